@@ -1,0 +1,914 @@
+/*
+ * lz4ref — CPU oracle (TEST INFRASTRUCTURE ONLY; see lz4ref.h).
+ *
+ * Scalar restatement of dart_lz4's block/frame hot path.  Each function cites
+ * the reference lines (path:line under lib/src) whose behaviour it follows.
+ */
+#include "lz4ref.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ status */
+
+const char *lz4ref_status_type(int s) {
+  if (s == LZ4REF_OK) return "OK";
+  if (s >= 1 && s < 10) return "Lz4FormatException";
+  if (s >= 10 && s < 30) return "Lz4CorruptDataException";
+  if (s == LZ4REF_LIMIT) return "Lz4OutputLimitException";
+  if (s >= 40 && s < 50) return "Lz4UnsupportedFeatureException";
+  if (s == LZ4REF_DICT_NOT_FOUND) return "Lz4Exception";
+  if (s == LZ4REF_RANGE) return "RangeError";
+  return "BackendError";
+}
+
+const char *lz4ref_status_message(int s) {
+  switch (s) {
+    case LZ4REF_OK: return "";
+    case LZ4REF_FORMAT_EOF: return "Unexpected end of input";
+    case LZ4REF_FORMAT_MAGIC: return "Invalid LZ4 frame magic number";
+    case LZ4REF_FORMAT_FLG_RESERVED: return "Reserved FLG bit is set";
+    case LZ4REF_FORMAT_BD_RESERVED: return "Reserved BD bits are set";
+    case LZ4REF_FORMAT_BLOCK_MAX: return "Invalid block maximum size";
+    case LZ4REF_FORMAT_INT_OVERFLOW: return "Integer overflow";
+    case LZ4REF_FORMAT_CONTENT_SIZE_ARG: return "contentSize does not match src length";
+    case LZ4REF_CORRUPT_LITERAL: return "Literal length exceeds output size";
+    case LZ4REF_CORRUPT_MATCH: return "Match length exceeds output size";
+    case LZ4REF_CORRUPT_TRAILING: return "Trailing bytes after end of block";
+    case LZ4REF_CORRUPT_DISTANCE: return "Invalid match distance";
+    case LZ4REF_CORRUPT_HEADER_CK: return "Header checksum mismatch";
+    case LZ4REF_CORRUPT_BLOCK_SIZE: return "Block size exceeds maximum";
+    case LZ4REF_CORRUPT_BLOCK_CK: return "Block checksum mismatch";
+    case LZ4REF_CORRUPT_CONTENT_CK: return "Content checksum mismatch";
+    case LZ4REF_CORRUPT_CONTENT_SIZE: return "Content size mismatch";
+    case LZ4REF_CORRUPT_LEGACY_SIZE: return "Invalid legacy block size";
+    case LZ4REF_CORRUPT_LEGACY_NOT_FULL: return "Legacy block is not full";
+    case LZ4REF_LIMIT: return "Output limit exceeded";
+    case LZ4REF_UNSUPPORTED_VERSION: return "Unsupported LZ4 frame version";
+    case LZ4REF_UNSUPPORTED_DICT:
+      return "Dictionary ID present but no dictionary resolver provided";
+    case LZ4REF_DICT_NOT_FOUND: return "Dictionary not found for ID: ";
+    case LZ4REF_RANGE: return "Invalid argument";
+    case LZ4REF_DST_TOO_SMALL: return "destination buffer too small";
+    default: return "unknown";
+  }
+}
+
+/* ------------------------------------------------------- byte sink (writer)
+ * Semantics of ByteWriter (internal/byte_writer.dart:5-154) that are visible
+ * on the path: append, maxLength -> 'Output limit exceeded' (:128-132),
+ * copyMatch (:93-121).  The growth policy is replaced by a caller buffer of
+ * physical capacity `cap`. */
+typedef struct {
+  uint8_t *buf;
+  size_t len;
+  size_t cap;      /* physical capacity of buf */
+  int64_t max_len; /* ByteWriter maxLength, <0 = none */
+} sink_t;
+
+static int sink_reserve(sink_t *w, size_t add) {
+  if (w->max_len >= 0 && (uint64_t)w->len + add > (uint64_t)w->max_len)
+    return LZ4REF_LIMIT;
+  if (w->len + add > w->cap) return LZ4REF_DST_TOO_SMALL;
+  return LZ4REF_OK;
+}
+
+static int sink_put(sink_t *w, const uint8_t *p, size_t n) {
+  int st = sink_reserve(w, n);
+  if (st) return st;
+  if (n) memcpy(w->buf + w->len, p, n);
+  w->len += n;
+  return LZ4REF_OK;
+}
+
+static int sink_u8(sink_t *w, uint32_t v) {
+  uint8_t b = (uint8_t)v;
+  return sink_put(w, &b, 1);
+}
+
+static int sink_u32le(sink_t *w, uint32_t v) {
+  uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
+  return sink_put(w, b, 4);
+}
+
+/* byte_writer.dart:93-121 — distance validated before capacity. */
+static int sink_copy_match(sink_t *w, size_t distance, size_t match_len) {
+  if (distance == 0 || distance > w->len) return LZ4REF_CORRUPT_DISTANCE;
+  if (match_len == 0) return LZ4REF_OK;
+  int st = sink_reserve(w, match_len);
+  if (st) return st;
+  uint8_t *d = w->buf + w->len;
+  const uint8_t *s = d - distance;
+  for (size_t k = 0; k < match_len; k++) d[k] = s[k]; /* byte-serial forward copy */
+  w->len += match_len;
+  return LZ4REF_OK;
+}
+
+/* --------------------------------------------------------------- byte source
+ * ByteReader (internal/byte_reader.dart): every short read is FORMAT_EOF. */
+typedef struct {
+  const uint8_t *p;
+  size_t len;
+  size_t off;
+} src_t;
+
+static size_t src_remaining(const src_t *r) { return r->len - r->off; }
+static int src_eof(const src_t *r) { return r->off >= r->len; }
+
+static int src_u8(src_t *r, uint32_t *v) {
+  if (src_remaining(r) < 1) return LZ4REF_FORMAT_EOF;
+  *v = r->p[r->off++];
+  return LZ4REF_OK;
+}
+static int src_u16le(src_t *r, uint32_t *v) {
+  if (src_remaining(r) < 2) return LZ4REF_FORMAT_EOF;
+  *v = (uint32_t)r->p[r->off] | ((uint32_t)r->p[r->off + 1] << 8);
+  r->off += 2;
+  return LZ4REF_OK;
+}
+static int src_u32le(src_t *r, uint32_t *v) {
+  if (src_remaining(r) < 4) return LZ4REF_FORMAT_EOF;
+  const uint8_t *q = r->p + r->off;
+  *v = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+  r->off += 4;
+  return LZ4REF_OK;
+}
+static int src_view(src_t *r, uint64_t count, const uint8_t **v) {
+  if (count > src_remaining(r)) return LZ4REF_FORMAT_EOF;
+  *v = r->p + r->off;
+  r->off += (size_t)count;
+  return LZ4REF_OK;
+}
+
+/* ------------------------------------------------------------------- xxh32
+ * xxhash/xxh32.dart: primes :3-7, one-shot :166-240, streaming :21-164,
+ * round :242-247.  _mul32 (:9-19) is a plain multiply modulo 2^32. */
+#define P1 0x9E3779B1u
+#define P2 0x85EBCA77u
+#define P3 0xC2B2AE3Du
+#define P4 0x27D4EB2Fu
+#define P5 0x165667B1u
+
+static uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static uint32_t rd32(const uint8_t *p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+static uint32_t xxh_round(uint32_t acc, uint32_t x) {
+  acc += x * P2;
+  acc = rotl32(acc, 13);
+  return acc * P1;
+}
+static uint32_t xxh_tail(uint32_t h, const uint8_t *p, size_t len) {
+  size_t k = 0;
+  while (k + 4 <= len) { /* :221-225 */
+    h += rd32(p + k) * P3;
+    h = rotl32(h, 17) * P4;
+    k += 4;
+  }
+  while (k < len) { /* :227-231 */
+    h += (uint32_t)p[k] * P5;
+    h = rotl32(h, 11) * P1;
+    k++;
+  }
+  h ^= h >> 15; /* :233-237 */
+  h *= P2;
+  h ^= h >> 13;
+  h *= P3;
+  h ^= h >> 16;
+  return h;
+}
+
+uint32_t lz4ref_xxh32(const uint8_t *p, size_t len, uint32_t seed) {
+  size_t k = 0;
+  uint32_t h;
+  if (len >= 16) {
+    uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+    size_t limit = len - 16;
+    while (k <= limit) {
+      v1 = xxh_round(v1, rd32(p + k));
+      v2 = xxh_round(v2, rd32(p + k + 4));
+      v3 = xxh_round(v3, rd32(p + k + 8));
+      v4 = xxh_round(v4, rd32(p + k + 12));
+      k += 16;
+    }
+    h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+  } else {
+    h = seed + P5;
+  }
+  h += (uint32_t)len;
+  return xxh_tail(h, p + k, len - k);
+}
+
+void lz4ref_xxh32_init(lz4ref_xxh32_state *s, uint32_t seed) { /* :33-41 */
+  s->seed = seed;
+  s->v1 = seed + P1 + P2;
+  s->v2 = seed + P2;
+  s->v3 = seed;
+  s->v4 = seed - P1;
+  s->total_len = 0;
+  s->mem_size = 0;
+  memset(s->mem, 0, sizeof s->mem);
+}
+
+void lz4ref_xxh32_update(lz4ref_xxh32_state *s, const uint8_t *p, size_t len) { /* :43-125 */
+  if (len == 0) return;
+  s->total_len += len;
+  if (s->mem_size + len < 16) {
+    memcpy(s->mem + s->mem_size, p, len);
+    s->mem_size += (uint32_t)len;
+    return;
+  }
+  if (s->mem_size != 0) {
+    size_t fill = 16 - s->mem_size;
+    memcpy(s->mem + s->mem_size, p, fill);
+    p += fill;
+    len -= fill;
+    s->mem_size = 0;
+    s->v1 = xxh_round(s->v1, rd32(s->mem));
+    s->v2 = xxh_round(s->v2, rd32(s->mem + 4));
+    s->v3 = xxh_round(s->v3, rd32(s->mem + 8));
+    s->v4 = xxh_round(s->v4, rd32(s->mem + 12));
+  }
+  while (len >= 16) {
+    s->v1 = xxh_round(s->v1, rd32(p));
+    s->v2 = xxh_round(s->v2, rd32(p + 4));
+    s->v3 = xxh_round(s->v3, rd32(p + 8));
+    s->v4 = xxh_round(s->v4, rd32(p + 12));
+    p += 16;
+    len -= 16;
+  }
+  if (len) {
+    memcpy(s->mem, p, len);
+    s->mem_size = (uint32_t)len;
+  }
+}
+
+uint32_t lz4ref_xxh32_digest(const lz4ref_xxh32_state *s) { /* :127-163 */
+  uint32_t h;
+  if (s->total_len >= 16)
+    h = rotl32(s->v1, 1) + rotl32(s->v2, 7) + rotl32(s->v3, 12) + rotl32(s->v4, 18);
+  else
+    h = s->seed + P5;
+  h += (uint32_t)s->total_len;
+  return xxh_tail(h, s->mem, s->mem_size);
+}
+
+/* ------------------------------------------------------ sequence emission
+ * block/lz4_block_encoder.dart:172-223 (identical copy in the HC encoder,
+ * hc/lz4_hc_block_encoder.dart:212-267). */
+static int emit_length(sink_t *w, size_t length) { /* :216-223 */
+  int st;
+  while (length >= 255) {
+    if ((st = sink_u8(w, 255))) return st;
+    length -= 255;
+  }
+  return sink_u8(w, (uint32_t)length);
+}
+
+static int emit_sequence(sink_t *w, const uint8_t *in, size_t lit_start, size_t lit_len,
+                         size_t distance, size_t match_len) { /* :172-200 */
+  int st;
+  size_t m4 = match_len - 4;
+  uint32_t tl = lit_len < 15 ? (uint32_t)lit_len : 15;
+  uint32_t tm = m4 < 15 ? (uint32_t)m4 : 15;
+  if ((st = sink_u8(w, (tl << 4) | tm))) return st;
+  if (lit_len >= 15 && (st = emit_length(w, lit_len - 15))) return st;
+  if (lit_len && (st = sink_put(w, in + lit_start, lit_len))) return st;
+  if ((st = sink_u8(w, (uint32_t)(distance & 0xff)))) return st;
+  if ((st = sink_u8(w, (uint32_t)((distance >> 8) & 0xff)))) return st;
+  if (m4 >= 15 && (st = emit_length(w, m4 - 15))) return st;
+  return LZ4REF_OK;
+}
+
+static int emit_last_literals(sink_t *w, const uint8_t *in, size_t start, size_t length) { /* :202-214 */
+  int st;
+  uint32_t tl = length < 15 ? (uint32_t)length : 15;
+  if ((st = sink_u8(w, tl << 4))) return st;
+  if (length >= 15 && (st = emit_length(w, length - 15))) return st;
+  if (length && (st = sink_put(w, in + start, length))) return st;
+  return LZ4REF_OK;
+}
+
+size_t lz4ref_compress_bound(size_t n) { return n + n / 255 + 16; }
+
+static uint32_t hash16(uint32_t seq) { return (seq * 2654435761u) >> 16; } /* :167-170 */
+
+/* dict‖src work buffer (:50-72): dictionary trimmed to its last 65535 bytes. */
+static const uint8_t *make_input(const uint8_t *src, size_t n, const uint8_t *dict,
+                                 size_t dict_len, size_t *dict_used, uint8_t **owned) {
+  *owned = NULL;
+  if (dict == NULL || dict_len == 0) {
+    *dict_used = 0;
+    return src;
+  }
+  if (dict_len > 65535) {
+    dict += dict_len - 65535;
+    dict_len = 65535;
+  }
+  uint8_t *buf = (uint8_t *)malloc(dict_len + n);
+  if (!buf) return NULL;
+  memcpy(buf, dict, dict_len);
+  memcpy(buf + dict_len, src, n);
+  *dict_used = dict_len;
+  *owned = buf;
+  return buf;
+}
+
+/* ------------------------------------------------------ fast block encoder
+ * block/lz4_block_encoder.dart:35-157. */
+static int fast_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                               size_t dict_len_in, int64_t acceleration) {
+  if (acceleration < 1) return LZ4REF_RANGE; /* :41-43, before the empty check */
+  if (n == 0) return LZ4REF_OK;              /* :45-48 */
+
+  size_t dict_len;
+  uint8_t *owned;
+  const uint8_t *in = make_input(src, n, dict, dict_len_in, &dict_len, &owned);
+  if (!in) return LZ4REF_DST_TOO_SMALL;
+  int st = LZ4REF_OK;
+  int32_t *table = NULL;
+
+  if (n < 4) { /* :74-78 */
+    st = emit_last_literals(w, in, dict_len, n);
+    goto done;
+  }
+  table = (int32_t *)malloc(65536 * sizeof(int32_t));
+  if (!table) { st = LZ4REF_DST_TOO_SMALL; goto done; }
+  for (int k = 0; k < 65536; k++) table[k] = -1; /* :80-81 */
+
+  if (dict_len != 0) /* :83-88 */
+    for (size_t pos = 0; pos + 4 <= dict_len; pos++) table[hash16(rd32(in + pos))] = (int32_t)pos;
+
+  {
+    size_t total = dict_len + n;
+    size_t anchor = dict_len, i = dict_len;
+    /* Dart's >> on a non-negative int yields 0 for shift counts >= 64 */
+    unsigned sh = acceleration > 62 ? 63 : (unsigned)acceleration;
+    while (i + 4 <= total) { /* :95 */
+      uint32_t seq = rd32(in + i);
+      uint32_t h = hash16(seq);
+      int32_t ref = table[h];
+      table[h] = (int32_t)i; /* :100 unconditional */
+      if (ref >= 0 && i - (size_t)ref <= 0xFFFF && rd32(in + ref) == seq) { /* :102-103 */
+        size_t ms = i, rs = (size_t)ref;
+        while (ms > anchor && rs > 0 && in[ms - 1] == in[rs - 1]) { ms--; rs--; } /* :107-113 */
+        size_t ml = 4;
+        while (ms + ml < total && in[ms + ml] == in[rs + ml]) ml++; /* :117-121 */
+        if ((st = emit_sequence(w, in, anchor, ms - anchor, ms - rs, ml))) goto done;
+        i = ms + ml;
+        anchor = i;
+        if (i + 4 > total) break; /* :135-137 */
+        for (size_t j = i - ml + 1; j + 4 <= i; j++) /* :139-145 */
+          table[hash16(rd32(in + j))] = (int32_t)j;
+        continue;
+      }
+      i += 1 + (size_t)(((uint64_t)(i - anchor)) >> sh); /* :150 */
+    }
+    if (total - anchor != 0) /* :153-156 */
+      st = emit_last_literals(w, in, anchor, total - anchor);
+  }
+done:
+  free(table);
+  free(owned);
+  return st;
+}
+
+int lz4ref_block_compress_fast(const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
+                               int64_t acceleration, uint8_t *dst, size_t cap, size_t *out_len) {
+  sink_t w = {dst, 0, cap, -1};
+  int st = fast_encode_to_sink(&w, src, n, dict, dict_len, acceleration);
+  if (out_len) *out_len = w.len;
+  return st;
+}
+
+/* -------------------------------------------------------- HC block encoder
+ * hc/lz4_hc_block_encoder.dart:49-197; options hc/lz4_hc_options.dart:10-16. */
+static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                             size_t dict_len_in, int64_t max_depth) {
+  if (max_depth < 1) return LZ4REF_RANGE; /* Lz4HcOptions ctor */
+  if (n == 0) return LZ4REF_OK;           /* :57-60 */
+
+  size_t dict_len;
+  uint8_t *owned;
+  const uint8_t *in = make_input(src, n, dict, dict_len_in, &dict_len, &owned);
+  if (!in) return LZ4REF_DST_TOO_SMALL;
+  int st = LZ4REF_OK;
+  int32_t *head = NULL, *chain = NULL;
+
+  if (n < 4) { /* :86-90 */
+    st = emit_last_literals(w, in, dict_len, n);
+    goto done;
+  }
+  {
+    size_t total = dict_len + n;
+    head = (int32_t *)malloc(65536 * sizeof(int32_t));
+    chain = (int32_t *)malloc(total * sizeof(int32_t));
+    if (!head || !chain) { st = LZ4REF_DST_TOO_SMALL; goto done; }
+    for (int k = 0; k < 65536; k++) head[k] = -1;       /* :92-93 */
+    for (size_t k = 0; k < total; k++) chain[k] = -1;    /* :94, :34 */
+
+#define HC_INSERT(pos, refvar)                       \
+  do {                                               \
+    uint32_t h_ = hash16(rd32(in + (pos)));          \
+    (refvar) = head[h_];                             \
+    chain[(pos)] = (refvar);                         \
+    head[h_] = (int32_t)(pos);                       \
+  } while (0) /* :96-103 */
+
+    int32_t tmp;
+    if (dict_len != 0)
+      for (size_t pos = 0; pos + 4 <= dict_len; pos++) HC_INSERT(pos, tmp); /* :105-109 */
+
+    size_t anchor = dict_len, i = dict_len;
+    while (i + 4 <= total) { /* :116 */
+      int32_t cand;
+      HC_INSERT(i, cand);
+      size_t best_len = 0;
+      int32_t best_ref = -1;
+      int64_t depth = 0;
+      uint32_t seq_i = rd32(in + i);
+      while (cand >= 0 && depth < max_depth) { /* :123 */
+        if (i - (size_t)cand > 0xFFFF) { /* :125-129: far candidates still count depth */
+          cand = chain[cand];
+          depth++;
+          continue;
+        }
+        if (rd32(in + cand) == seq_i) { /* :131 */
+          size_t ml = 4;
+          while (i + ml < total && in[i + ml] == in[(size_t)cand + ml]) ml++;
+          if (ml > best_len) { /* strict: nearest wins ties */
+            best_len = ml;
+            best_ref = cand;
+            if (i + best_len == total) break; /* :140-142 */
+          }
+        }
+        cand = chain[cand];
+        depth++;
+      }
+      if (best_len >= 4) { /* :150 */
+        size_t ms = i, rs = (size_t)best_ref, al = best_len;
+        while (ms > anchor && rs > 0 && in[ms - 1] == in[rs - 1]) { ms--; rs--; al++; } /* :155-161 */
+        if ((st = emit_sequence(w, in, anchor, ms - anchor, ms - rs, al))) goto done;
+        i = ms + al;
+        anchor = i;
+        if (i + 4 > total) break; /* :176-178 */
+        for (size_t j = i - al + 1; j + 4 <= i; j++) HC_INSERT(j, tmp); /* :180-185 */
+        continue;
+      }
+      i++; /* :190 */
+    }
+    if (total - anchor != 0) st = emit_last_literals(w, in, anchor, total - anchor); /* :193-196 */
+  }
+done:
+  free(head);
+  free(chain);
+  free(owned);
+  return st;
+}
+
+int lz4ref_block_compress_hc(const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
+                             int64_t max_search_depth, uint8_t *dst, size_t cap, size_t *out_len) {
+  sink_t w = {dst, 0, cap, -1};
+  int st = hc_encode_to_sink(&w, src, n, dict, dict_len, max_search_depth);
+  if (out_len) *out_len = w.len;
+  return st;
+}
+
+/* ------------------------------------------------------------ block decoder */
+
+static int read_ext_length(src_t *r, uint64_t *total) { /* lz4_block_decoder.dart:121-130 */
+  uint64_t t = 0;
+  for (;;) {
+    uint32_t b;
+    int st = src_u8(r, &b);
+    if (st) return st;
+    t += b;
+    if (b != 255) break;
+  }
+  *total = t;
+  return LZ4REF_OK;
+}
+
+/* strict: lz4_block_decoder.dart:7-77 */
+int lz4ref_block_decompress(const uint8_t *src, size_t c, uint8_t *dst, int64_t size) {
+  if (size < 0) return LZ4REF_RANGE; /* :11-13 */
+  src_t r = {src, c, 0};
+  sink_t w = {dst, 0, (size_t)size, size};
+  int st;
+  while (w.len < (size_t)size) { /* :21 */
+    if (src_eof(&r)) return LZ4REF_FORMAT_EOF; /* :22-24 */
+    uint32_t token;
+    if ((st = src_u8(&r, &token))) return st;
+    uint64_t lit = token >> 4;
+    if (lit == 15) {
+      uint64_t e;
+      if ((st = read_ext_length(&r, &e))) return st;
+      lit += e;
+    }
+    if (lit > (uint64_t)size - w.len) return LZ4REF_CORRUPT_LITERAL; /* :33-35 */
+    if (lit != 0) {
+      const uint8_t *v;
+      if ((st = src_view(&r, lit, &v))) return st;
+      if ((st = sink_put(&w, v, (size_t)lit))) return st;
+    }
+    if (w.len == (size_t)size) { /* :42-48 */
+      if (!src_eof(&r)) return LZ4REF_CORRUPT_TRAILING;
+      return LZ4REF_OK;
+    }
+    if (src_remaining(&r) < 2) return LZ4REF_FORMAT_EOF; /* :50-52 */
+    uint32_t distance;
+    if ((st = src_u16le(&r, &distance))) return st;
+    uint64_t ml = (token & 15) + 4;
+    if ((token & 15) == 15) {
+      uint64_t e;
+      if ((st = read_ext_length(&r, &e))) return st;
+      ml += e;
+    }
+    if (ml > (uint64_t)size - w.len) return LZ4REF_CORRUPT_MATCH; /* :61-63 */
+    st = sink_copy_match(&w, distance, (size_t)ml);
+    if (st == LZ4REF_LIMIT) return LZ4REF_CORRUPT_MATCH; /* :65-69 */
+    if (st) return st;
+  }
+  if (!src_eof(&r)) return LZ4REF_CORRUPT_TRAILING; /* :72-74 */
+  return LZ4REF_OK;
+}
+
+/* lenient: lz4_block_decoder.dart:79-119, into a writer that may hold a prefix */
+static int decode_into_sink(const uint8_t *src, size_t c, sink_t *w) {
+  src_t r = {src, c, 0};
+  int st;
+  for (;;) {
+    if (src_eof(&r)) return LZ4REF_OK; /* :86-88 */
+    uint32_t token;
+    if ((st = src_u8(&r, &token))) return st;
+    uint64_t lit = token >> 4;
+    if (lit == 15) {
+      uint64_t e;
+      if ((st = read_ext_length(&r, &e))) return st;
+      lit += e;
+    }
+    if (lit != 0) { /* :97-100: reader truncation is raised before the writer cap */
+      const uint8_t *v;
+      if ((st = src_view(&r, lit, &v))) return st;
+      if (lit > (uint64_t)SIZE_MAX) return LZ4REF_LIMIT;
+      if ((st = sink_put(w, v, (size_t)lit))) return st;
+    }
+    if (src_eof(&r)) return LZ4REF_OK;                   /* :102-104 */
+    if (src_remaining(&r) < 2) return LZ4REF_FORMAT_EOF; /* :106-108 */
+    uint32_t distance;
+    if ((st = src_u16le(&r, &distance))) return st;
+    uint64_t ml = (token & 15) + 4;
+    if ((token & 15) == 15) {
+      uint64_t e;
+      if ((st = read_ext_length(&r, &e))) return st;
+      ml += e;
+    }
+    if (distance == 0 || distance > w->len) return LZ4REF_CORRUPT_DISTANCE;
+    if (w->max_len >= 0 && (uint64_t)w->len + ml > (uint64_t)w->max_len) return LZ4REF_LIMIT;
+    if ((st = sink_copy_match(w, distance, (size_t)ml))) return st; /* :117 */
+  }
+}
+
+int lz4ref_block_decompress_into(const uint8_t *src, size_t c, uint8_t *dst, size_t prefix_len,
+                                 size_t max_len, size_t *out_len) {
+  sink_t w = {dst, prefix_len, max_len, (int64_t)max_len};
+  int st = decode_into_sink(src, c, &w);
+  if (out_len) *out_len = w.len;
+  return st;
+}
+
+/* ----------------------------------------------------------- frame encoder */
+
+void lz4ref_frame_options_default(lz4ref_frame_options *o) { /* lz4_frame_options.dart:78-88 */
+  memset(o, 0, sizeof *o);
+  o->block_size_id = 7;
+  o->block_independence = 1;
+  o->acceleration = 1;
+  o->hc_max_search_depth = 64;
+}
+
+static size_t block_max_bytes(int id) { /* lz4_frame_options.dart:117-128 */
+  switch (id) {
+    case 4: return 64u * 1024;
+    case 5: return 256u * 1024;
+    case 6: return 1024u * 1024;
+    case 7: return 4u * 1024 * 1024;
+    default: return 0;
+  }
+}
+
+size_t lz4ref_frame_bound(size_t n, const lz4ref_frame_options *o) {
+  size_t bmax = block_max_bytes(o->block_size_id);
+  size_t nblocks = bmax ? (n + bmax - 1) / bmax : 0;
+  /* while a block is being compressed in place it may transiently reach
+   * compress_bound(block) before being rewound to the raw form */
+  return 19 + nblocks * 8 + n + 8 + lz4ref_compress_bound(bmax < n ? bmax : n);
+}
+
+/* lz4_frame_encoder.dart:105-274 */
+int lz4ref_frame_encode(const uint8_t *src, size_t n, const lz4ref_frame_options *o,
+                        const uint8_t *dict, size_t dict_len, uint8_t *dst, size_t cap,
+                        size_t *out_len) {
+  int st;
+  if (o->acceleration < 1) return LZ4REF_RANGE; /* options ctor :89-91 */
+  size_t bmax = block_max_bytes(o->block_size_id);
+  if (!bmax) return LZ4REF_RANGE;
+  sink_t w = {dst, 0, cap, -1};
+
+  uint32_t flg = (1u << 6) | ((o->block_independence ? 1u : 0u) << 5) |
+                 ((o->block_checksum ? 1u : 0u) << 4) | ((o->has_content_size ? 1u : 0u) << 3) |
+                 ((o->content_checksum ? 1u : 0u) << 2) | (o->has_dict_id ? 1u : 0u); /* :112-117 */
+  uint32_t bd = ((uint32_t)o->block_size_id & 7u) << 4;                                  /* :119 */
+  if ((st = sink_u32le(&w, 0x184D2204u))) return st;
+  if ((st = sink_u8(&w, flg))) return st;
+  if ((st = sink_u8(&w, bd))) return st;
+  if (o->has_content_size) { /* :128-133 */
+    if ((st = sink_u32le(&w, (uint32_t)(o->content_size & 0xFFFFFFFFu)))) return st;
+    if ((st = sink_u32le(&w, (uint32_t)(o->content_size >> 32)))) return st;
+  }
+  if (o->has_dict_id && (st = sink_u32le(&w, o->dict_id))) return st; /* :135-138 */
+  uint32_t hc = (lz4ref_xxh32(w.buf + 4, w.len - 4, 0) >> 8) & 0xff;  /* :140-144 */
+  if ((st = sink_u8(&w, hc))) return st;
+
+  lz4ref_xxh32_state content;
+  lz4ref_xxh32_init(&content, 0);
+
+  const size_t window = 64 * 1024;
+  uint8_t *combined = NULL;
+  size_t offset = 0;
+  while (offset < n) { /* :154 */
+    size_t end = offset + bmax;
+    if (end > n) end = n;
+    const uint8_t *chunk = src + offset;
+    size_t chunk_len = end - offset;
+    if (o->content_checksum) lz4ref_xxh32_update(&content, chunk, chunk_len); /* :162-164 */
+
+    const uint8_t *bdict = NULL;
+    size_t bdict_len = 0;
+    if (o->block_independence) { /* :167-169 */
+      bdict = dict;
+      bdict_len = dict ? dict_len : 0;
+    } else if (offset == 0) { /* :176-177 */
+      bdict = dict;
+      bdict_len = dict ? dict_len : 0;
+    } else if (offset >= window) { /* :178-180 */
+      bdict = src + offset - window;
+      bdict_len = window;
+    } else { /* :181-206 mixed history */
+      size_t dl = dict ? dict_len : 0;
+      if (dl == 0) {
+        bdict = src;
+        bdict_len = offset;
+      } else {
+        size_t needed = window - offset;
+        size_t take = dl > needed ? needed : dl;
+        free(combined);
+        combined = (uint8_t *)malloc(take + offset);
+        if (!combined) return LZ4REF_DST_TOO_SMALL;
+        memcpy(combined, dict + dl - take, take);
+        memcpy(combined + take, src, offset);
+        bdict = combined;
+        bdict_len = take + offset;
+      }
+    }
+
+    size_t block_start = w.len;
+    if ((st = sink_u32le(&w, 0))) goto fail; /* placeholder :210-211 */
+    size_t payload_start = w.len;
+    if (o->compression == 0)
+      st = fast_encode_to_sink(&w, chunk, chunk_len, bdict, bdict_len, o->acceleration);
+    else
+      st = hc_encode_to_sink(&w, chunk, chunk_len, bdict, bdict_len, o->hc_max_search_depth);
+    if (st) goto fail;
+
+    size_t clen = w.len - payload_start;
+    if (clen < chunk_len) { /* :235-247 */
+      uint32_t v = (uint32_t)clen;
+      w.buf[block_start] = (uint8_t)v;
+      w.buf[block_start + 1] = (uint8_t)(v >> 8);
+      w.buf[block_start + 2] = (uint8_t)(v >> 16);
+      w.buf[block_start + 3] = (uint8_t)(v >> 24);
+      if (o->block_checksum &&
+          (st = sink_u32le(&w, lz4ref_xxh32(w.buf + payload_start, clen, 0))))
+        goto fail;
+    } else { /* :248-258 */
+      w.len = block_start;
+      if ((st = sink_u32le(&w, 0x80000000u | (uint32_t)chunk_len))) goto fail;
+      if ((st = sink_put(&w, chunk, chunk_len))) goto fail;
+      if (o->block_checksum && (st = sink_u32le(&w, lz4ref_xxh32(chunk, chunk_len, 0)))) goto fail;
+    }
+    offset = end;
+  }
+  free(combined);
+  combined = NULL;
+
+  if ((st = sink_u32le(&w, 0))) return st; /* :263 */
+  if (o->content_checksum && (st = sink_u32le(&w, lz4ref_xxh32_digest(&content)))) return st;
+  if (o->has_content_size && (uint64_t)n != o->content_size) /* :269-271, after all work */
+    return LZ4REF_FORMAT_CONTENT_SIZE_ARG;
+  if (out_len) *out_len = w.len;
+  return LZ4REF_OK;
+fail:
+  free(combined);
+  return st;
+}
+
+/* ----------------------------------------------------------- frame decoder
+ * lz4_frame_decoder.dart:27-398. */
+typedef struct {
+  src_t r;
+  sink_t out;              /* _out, maxLength = maxOutputBytes */
+  int64_t max_output;      /* <0 = null */
+  lz4ref_dict_resolver resolver;
+  void *user;
+  int have_dict;           /* _dict != null; persists across frames (:34,235) */
+  const uint8_t *dict;
+  size_t dict_len;
+  uint32_t err_dict_id;
+} fdec_t;
+
+static int is_legacy_boundary(uint32_t magic) { /* :150-155 */
+  if (magic == 0x184D2204u || magic == 0x184C2102u) return 1;
+  return (magic & 0xFFFFFFF0u) == 0x184D2A50u;
+}
+
+static uint32_t peek_u32(const src_t *r) { return rd32(r->p + r->off); }
+
+static int decode_legacy_frame(fdec_t *d) { /* :86-136 */
+  const size_t legacy_max = 8u * 1024 * 1024;
+  size_t frame_start = d->out.len;
+  uint8_t *tmp = (uint8_t *)malloc(legacy_max);
+  if (!tmp) return LZ4REF_DST_TOO_SMALL;
+  int st = LZ4REF_OK;
+  for (;;) {
+    if (src_remaining(&d->r) == 0) break;
+    if (src_remaining(&d->r) < 4) { st = LZ4REF_FORMAT_EOF; break; }
+    if (is_legacy_boundary(peek_u32(&d->r))) break;
+    uint32_t csize;
+    if ((st = src_u32le(&d->r, &csize))) break;
+    if (csize == 0) { st = LZ4REF_CORRUPT_LEGACY_SIZE; break; }
+    const uint8_t *payload;
+    if ((st = src_view(&d->r, csize, &payload))) break;
+    sink_t t = {tmp, 0, legacy_max, (int64_t)legacy_max};
+    if ((st = decode_into_sink(payload, csize, &t))) break;
+    if ((st = sink_put(&d->out, tmp, t.len))) break;
+    if (src_remaining(&d->r) == 0) break;
+    if (src_remaining(&d->r) < 4) { st = LZ4REF_FORMAT_EOF; break; }
+    if (!is_legacy_boundary(peek_u32(&d->r)) && t.len != legacy_max) {
+      st = LZ4REF_CORRUPT_LEGACY_NOT_FULL;
+      break;
+    }
+  }
+  free(tmp);
+  (void)frame_start;
+  return st;
+}
+
+static int decode_standard_frame(fdec_t *d) { /* :157-324 */
+  int st;
+  src_t *r = &d->r;
+  size_t frame_start = d->out.len; /* frameOut is a view of _out past this point */
+  size_t desc_start = r->off;
+  if (src_remaining(r) < 3) return LZ4REF_FORMAT_EOF; /* :168-170 */
+  uint32_t flg = 0, bd = 0;
+  src_u8(r, &flg);
+  src_u8(r, &bd);
+  if (((flg >> 6) & 3) != 1) return LZ4REF_UNSUPPORTED_VERSION; /* :175-179 */
+  int indep = (flg >> 5) & 1, block_ck = (flg >> 4) & 1, has_size = (flg >> 3) & 1;
+  int content_ck = (flg >> 2) & 1, has_dict = flg & 1;
+  if ((flg >> 1) & 1) return LZ4REF_FORMAT_FLG_RESERVED; /* :188-190 */
+  if (bd & 0x8F) return LZ4REF_FORMAT_BD_RESERVED;       /* :192-194 */
+  size_t bmax = block_max_bytes((bd >> 4) & 7);
+  if (!bmax) return LZ4REF_FORMAT_BLOCK_MAX; /* :196-197, :385-398 */
+  uint64_t content_size = 0;
+  if (has_size) { /* :199-205 */
+    if (src_remaining(r) < 8) return LZ4REF_FORMAT_EOF;
+    uint32_t lo, hi;
+    src_u32le(r, &lo);
+    src_u32le(r, &hi);
+    content_size = ((uint64_t)hi << 32) | lo;
+    if (content_size >> 63) return LZ4REF_FORMAT_INT_OVERFLOW; /* byte_reader.dart:74-76 */
+  }
+  uint32_t dict_id = 0;
+  if (has_dict) { /* :207-213 */
+    if (src_remaining(r) < 4) return LZ4REF_FORMAT_EOF;
+    src_u32le(r, &dict_id);
+  }
+  size_t desc_end = r->off;
+  uint32_t hc;
+  if ((st = src_u8(r, &hc))) return st; /* :217 */
+  if (hc != ((lz4ref_xxh32(r->p + desc_start, desc_end - desc_start, 0) >> 8) & 0xff))
+    return LZ4REF_CORRUPT_HEADER_CK; /* :218-223 */
+  if (has_dict) { /* :225-236 */
+    if (!d->resolver) return LZ4REF_UNSUPPORTED_DICT;
+    const uint8_t *dp = NULL;
+    size_t dl = 0;
+    if (!d->resolver(d->user, dict_id, &dp, &dl)) {
+      d->err_dict_id = dict_id;
+      return LZ4REF_DICT_NOT_FOUND;
+    }
+    d->have_dict = 1;
+    d->dict = dp;
+    d->dict_len = dl;
+  }
+
+  const size_t window = 64 * 1024;
+  uint8_t *tmp = (uint8_t *)malloc(window + bmax);
+  if (!tmp) return LZ4REF_DST_TOO_SMALL;
+  st = LZ4REF_OK;
+  for (;;) { /* :238-304 */
+    if (src_remaining(r) < 4) { st = LZ4REF_FORMAT_EOF; break; }
+    uint32_t raw;
+    src_u32le(r, &raw);
+    if (raw == 0) break;
+    int stored = (raw & 0x80000000u) != 0;
+    uint32_t bsize = raw & 0x7FFFFFFFu;
+    if (bsize > bmax) { st = LZ4REF_CORRUPT_BLOCK_SIZE; break; } /* :251-253 */
+    const uint8_t *payload;
+    if ((st = src_view(r, bsize, &payload))) break; /* :255 */
+    if (block_ck) {                                  /* :257-266 */
+      uint32_t expected;
+      if ((st = src_u32le(r, &expected))) break;
+      if (lz4ref_xxh32(payload, bsize, 0) != expected) { st = LZ4REF_CORRUPT_BLOCK_CK; break; }
+    }
+    if (stored) { /* :268-271 */
+      if ((st = sink_put(&d->out, payload, bsize))) break;
+      continue;
+    }
+    if (indep) {
+      size_t eff = 0;
+      if (d->have_dict) { /* :275-290 — decoder keeps the last 65536 dictionary bytes */
+        eff = d->dict_len > window ? window : d->dict_len;
+        memcpy(tmp, d->dict + d->dict_len - eff, eff);
+      }
+      sink_t t = {tmp, eff, eff + bmax, (int64_t)(eff + bmax)};
+      if ((st = decode_into_sink(payload, bsize, &t))) break;
+      if ((st = sink_put(&d->out, tmp + eff, t.len - eff))) break;
+    } else { /* _decodeDependentBlock :326-382 */
+      size_t out_len = d->out.len - frame_start;
+      size_t hist = out_len < window ? out_len : window;
+      size_t prefix = 0;
+      if (hist < window && d->have_dict) {
+        size_t needed = window - hist;
+        size_t cl = d->dict_len < needed ? d->dict_len : needed;
+        memcpy(tmp, d->dict + d->dict_len - cl, cl);
+        prefix = cl;
+      }
+      memcpy(tmp + prefix, d->out.buf + d->out.len - hist, hist);
+      prefix += hist;
+      sink_t t = {tmp, prefix, prefix + bmax, (int64_t)(prefix + bmax)};
+      if ((st = decode_into_sink(payload, bsize, &t))) break;
+      if (t.len - prefix > bmax) { st = LZ4REF_CORRUPT_BLOCK_SIZE; break; }
+      if ((st = sink_put(&d->out, tmp + prefix, t.len - prefix))) break;
+    }
+  }
+  free(tmp);
+  if (st) return st;
+
+  if (content_ck) { /* :306-315 */
+    uint32_t expected;
+    if ((st = src_u32le(r, &expected))) return st;
+    if (lz4ref_xxh32(d->out.buf + frame_start, d->out.len - frame_start, 0) != expected)
+      return LZ4REF_CORRUPT_CONTENT_CK;
+  }
+  if (has_size && (uint64_t)(d->out.len - frame_start) != content_size) /* :317-321 */
+    return LZ4REF_CORRUPT_CONTENT_SIZE;
+  return LZ4REF_OK;
+}
+
+int lz4ref_frame_decode(const uint8_t *src, size_t len, int64_t max_output_bytes,
+                        lz4ref_dict_resolver resolver, void *user, uint8_t *dst, size_t cap,
+                        size_t *out_len, uint32_t *err_dict_id) {
+  fdec_t d;
+  memset(&d, 0, sizeof d);
+  d.r.p = src;
+  d.r.len = len;
+  d.out.buf = dst;
+  d.out.cap = cap;
+  d.out.max_len = max_output_bytes < 0 ? -1 : max_output_bytes;
+  d.max_output = max_output_bytes;
+  d.resolver = resolver;
+  d.user = user;
+  int st = LZ4REF_OK;
+  while (!src_eof(&d.r)) { /* :45-50 */
+    uint32_t magic;
+    if (src_remaining(&d.r) < 4) { st = LZ4REF_FORMAT_EOF; break; } /* :53-55 */
+    src_u32le(&d.r, &magic);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) { /* :59-62, :78-84 */
+      uint32_t size;
+      if ((st = src_u32le(&d.r, &size))) break;
+      const uint8_t *skip;
+      if ((st = src_view(&d.r, size, &skip))) break;
+      continue;
+    }
+    if (magic == 0x184C2102u) { /* :64-68 */
+      if ((st = decode_legacy_frame(&d))) break;
+      continue;
+    }
+    if (magic != 0x184D2204u) { st = LZ4REF_FORMAT_MAGIC; break; } /* :70-72 */
+    if ((st = decode_standard_frame(&d))) break;
+  }
+  if (out_len) *out_len = d.out.len;
+  if (err_dict_id) *err_dict_id = d.err_dict_id;
+  return st;
+}
