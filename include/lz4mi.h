@@ -1,0 +1,256 @@
+/*
+ * lz4mi — MI355X (gfx950) implementation of the dart_lz4 block/frame hot path.
+ *
+ * C ABI: plain pointers and sizes, caller-owned buffers, int32 status codes,
+ * no exceptions and no aborts across the boundary.  A dart:ffi shim (or any
+ * other FFI) binds exactly these entry points; each comment names the
+ * reference interface (path:line in the dart_lz4 checkout) it stands in for.
+ *
+ * Status codes map 1:1 to the Dart exception class + message the reference
+ * throws, so the host-language shim can rebuild the identical exception.
+ *
+ * Threading: every call takes an explicit context; a context owns one HIP
+ * stream and its device scratch, and is used by one thread at a time.
+ * Different contexts may be used concurrently (the reference keeps its scratch
+ * in isolate-local globals, lib/src/block/lz4_block_encoder.dart:9-11).
+ */
+#ifndef LZ4MI_H
+#define LZ4MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status
+ * lib/src/internal/lz4_exception.dart:2-35 (taxonomy); message sources:
+ * lib/src/block/lz4_block_decoder.dart:23,34,44,51,62,73,107;
+ * lib/src/internal/byte_writer.dart:98,131,146; byte_reader.dart:75,104;
+ * lib/src/frame/lz4_frame_decoder.dart:54,71,112,131,177,189,193,222,228,233,
+ * 252,264,313,319,396; lib/src/frame/lz4_frame_encoder.dart:270. */
+enum {
+  LZ4MI_OK = 0,
+  LZ4MI_FORMAT_EOF = 1,              /* Lz4FormatException 'Unexpected end of input' */
+  LZ4MI_FORMAT_MAGIC = 2,            /* 'Invalid LZ4 frame magic number' */
+  LZ4MI_FORMAT_FLG_RESERVED = 3,     /* 'Reserved FLG bit is set' */
+  LZ4MI_FORMAT_BD_RESERVED = 4,      /* 'Reserved BD bits are set' */
+  LZ4MI_FORMAT_BLOCK_MAX = 5,        /* 'Invalid block maximum size' */
+  LZ4MI_FORMAT_INT_OVERFLOW = 6,     /* 'Integer overflow' */
+  LZ4MI_FORMAT_CONTENT_SIZE_ARG = 7, /* 'contentSize does not match src length' */
+  LZ4MI_CORRUPT_LITERAL = 10,        /* Lz4CorruptDataException 'Literal length exceeds output size' */
+  LZ4MI_CORRUPT_MATCH = 11,          /* 'Match length exceeds output size' */
+  LZ4MI_CORRUPT_TRAILING = 12,       /* 'Trailing bytes after end of block' */
+  LZ4MI_CORRUPT_DISTANCE = 13,       /* 'Invalid match distance' */
+  LZ4MI_CORRUPT_HEADER_CK = 14,      /* 'Header checksum mismatch' */
+  LZ4MI_CORRUPT_BLOCK_SIZE = 15,     /* 'Block size exceeds maximum' */
+  LZ4MI_CORRUPT_BLOCK_CK = 16,       /* 'Block checksum mismatch' */
+  LZ4MI_CORRUPT_CONTENT_CK = 17,     /* 'Content checksum mismatch' */
+  LZ4MI_CORRUPT_CONTENT_SIZE = 18,   /* 'Content size mismatch' */
+  LZ4MI_CORRUPT_LEGACY_SIZE = 19,    /* 'Invalid legacy block size' */
+  LZ4MI_CORRUPT_LEGACY_NOT_FULL = 20,/* 'Legacy block is not full' */
+  LZ4MI_LIMIT = 30,                  /* Lz4OutputLimitException 'Output limit exceeded' */
+  LZ4MI_UNSUPPORTED_VERSION = 40,    /* Lz4UnsupportedFeatureException 'Unsupported LZ4 frame version' */
+  LZ4MI_UNSUPPORTED_DICT = 41,       /* '... no dictionary resolver provided' */
+  LZ4MI_DICT_NOT_FOUND = 50,         /* Lz4Exception 'Dictionary not found for ID: <id>' */
+  LZ4MI_RANGE = 60,                  /* Dart RangeError (argument validation) */
+  /* not reference errors */
+  LZ4MI_BACKEND = 70,                /* HIP runtime failure; see lz4mi_last_backend_error */
+  LZ4MI_DST_TOO_SMALL = 71,          /* caller's destination buffer cannot hold the result */
+  LZ4MI_NEED_DICT = 72,              /* lz4mi_frame_decode_next: call again with the dictionary */
+  LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent-block encode on device) */
+};
+
+/* Dart exception class name / message for a status (static strings). */
+const char *lz4mi_status_type(int32_t status);
+const char *lz4mi_status_message(int32_t status);
+
+/* ----------------------------------------------------------------- context */
+typedef struct lz4mi_ctx lz4mi_ctx;
+
+/* device: HIP device ordinal.  stream: a hipStream_t to run on, or NULL for a
+ * stream owned by the context.  Fails with LZ4MI_BACKEND when no GPU is usable. */
+int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **out);
+void lz4mi_ctx_destroy(lz4mi_ctx *ctx);
+int32_t lz4mi_ctx_synchronize(lz4mi_ctx *ctx);
+const char *lz4mi_last_backend_error(lz4mi_ctx *ctx);
+/* nonzero when built with the HIP kernels for gfx950 (always, in this build) */
+int32_t lz4mi_version(void);
+
+/* worst case of the fast/HC block encoders: n + n/255 + 16
+ * (all-literal block, lib/src/block/lz4_block_encoder.dart:202-223). */
+size_t lz4mi_compress_bound(size_t n);
+
+/* ----------------------------------------------- single block, host buffers
+ * These four are what the façade functions call.
+ *
+ * lz4Compress(level: fast)  lib/dart_lz4.dart:60-72 ->
+ *   lz4BlockCompress        lib/src/block/lz4_block_encoder.dart:24-157
+ * acceleration < 1 -> LZ4MI_RANGE even when n == 0 (:41-48).  dict may be NULL. */
+int32_t lz4mi_block_compress_fast(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
+                                  const uint8_t *dict, size_t dict_len, int64_t acceleration,
+                                  uint8_t *dst, size_t cap, size_t *out_len);
+
+/* lz4Compress(level: hc) -> lz4HcBlockCompress  lib/src/hc/lz4_hc_block_encoder.dart:38-197;
+ * max_search_depth < 1 -> LZ4MI_RANGE (lib/src/hc/lz4_hc_options.dart:13-15). */
+int32_t lz4mi_block_compress_hc(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
+                                const uint8_t *dict, size_t dict_len, int64_t max_search_depth,
+                                uint8_t *dst, size_t cap, size_t *out_len);
+
+/* lz4Decompress  lib/dart_lz4.dart:80-85 -> lz4BlockDecompress
+ * lib/src/block/lz4_block_decoder.dart:7-77 (strict: exact size, trailing-byte check).
+ * dst must hold decompressed_size bytes. */
+int32_t lz4mi_block_decompress(lz4mi_ctx *ctx, const uint8_t *src, size_t c,
+                               uint8_t *dst, int64_t decompressed_size);
+
+/* lz4BlockDecompressInto  lib/src/block/lz4_block_decoder.dart:79-119 with a
+ * ByteWriter(maxLength: max_len) already holding dst[0..prefix_len)
+ * (lib/src/frame/lz4_frame_decoder.dart:284-286).  *out_len = final writer length. */
+int32_t lz4mi_block_decompress_into(lz4mi_ctx *ctx, const uint8_t *src, size_t c,
+                                    uint8_t *dst, size_t prefix_len, size_t max_len,
+                                    size_t *out_len);
+
+/* xxh32  lib/src/xxhash/xxh32.dart:166-240 (one-shot, host buffer, computed on the GPU). */
+int32_t lz4mi_xxh32(lz4mi_ctx *ctx, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out);
+
+/* ------------------------------------------------ batches, device-resident
+ * The per-block loop bodies of the frame encoder/decoder
+ * (lib/src/frame/lz4_frame_encoder.dart:154-261, lz4_frame_decoder.dart:238-304)
+ * as one launch over many independent blocks.  All pointers prefixed d_ are
+ * device memory; work is enqueued on the context's stream and NOT synchronised.
+ *
+ * Block b reads  d_src + (d_src_off ? d_src_off[b] : b * src_stride), d_src_len[b] bytes
+ * (d_src_len NULL: every block src_len_uniform bytes, the last one shortened to
+ * src_total), and writes at d_dst + (d_dst_off ? d_dst_off[b] : b * dst_stride).
+ */
+typedef struct {
+  const uint8_t *d_src;
+  const uint64_t *d_src_off; /* optional */
+  const uint32_t *d_src_len; /* optional */
+  uint64_t src_stride;
+  uint32_t src_len_uniform;
+  uint64_t src_total;        /* used with src_len_uniform: total bytes over all blocks */
+  uint8_t *d_dst;
+  const uint64_t *d_dst_off; /* optional */
+  uint64_t dst_stride;
+  const uint32_t *d_dst_cap; /* optional per-block capacity / expected size */
+  uint32_t dst_cap_uniform;
+  const uint8_t *d_dict;     /* optional shared dictionary / history prefix */
+  uint32_t dict_len;
+  uint32_t nblocks;
+  uint32_t *d_out_len;       /* per block: bytes produced (excluding the prefix) */
+  int32_t *d_status;         /* per block: LZ4MI_* */
+} lz4mi_batch;
+
+/* lz4BlockCompressToWriter per block (lib/src/block/lz4_block_encoder.dart:35-157).
+ * Every block needs capacity >= lz4mi_compress_bound(len) or gets LZ4MI_DST_TOO_SMALL. */
+int32_t lz4mi_compress_fast_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int64_t acceleration);
+
+/* lz4HcBlockCompressToWriter per block (lib/src/hc/lz4_hc_block_encoder.dart:49-197). */
+int32_t lz4mi_compress_hc_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int64_t max_search_depth);
+
+/* strict != 0: lz4BlockDecompress, capacity = exact decompressed size.
+ * strict == 0: lz4BlockDecompressInto, capacity = ByteWriter maxLength minus the
+ * prefix; the shared d_dict (last 65536 bytes used) is the pre-filled prefix. */
+int32_t lz4mi_decompress_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t strict);
+
+/* xxh32 of each block's source bytes (seed 0): block checksums
+ * (lib/src/frame/lz4_frame_encoder.dart:242-257, lz4_frame_decoder.dart:257-266).
+ * Only d_src/d_src_off/d_src_len/src_* /nblocks are read; d_hash receives nblocks words. */
+int32_t lz4mi_xxh32_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, uint32_t *d_hash);
+
+/* Single-stream xxh32 over device memory (content checksum,
+ * lib/src/frame/lz4_frame_encoder.dart:148,163,266; lz4_frame_decoder.dart:311). */
+int32_t lz4mi_xxh32_device(lz4mi_ctx *ctx, const uint8_t *d_data, uint64_t len, uint32_t seed,
+                           uint32_t *d_out);
+
+/* ------------------------------------------------------------------- frames
+ * Mirrors Lz4FrameOptions (lib/src/frame/lz4_frame_options.dart:38-101);
+ * block_size_id is Lz4FrameBlockSize.bdId 4..7 (:104-115). */
+typedef struct {
+  int32_t block_size_id;      /* 4=64KiB 5=256KiB 6=1MiB 7=4MiB (default 7) */
+  int32_t block_independence; /* default 1 */
+  int32_t block_checksum;
+  int32_t content_checksum;
+  int32_t has_content_size;
+  int32_t has_dict_id;
+  int32_t compression;        /* 0 fast, 1 hc  (Lz4FrameCompression) */
+  int32_t acceleration;       /* default 1 */
+  int32_t hc_max_search_depth;/* default 64 */
+  uint32_t dict_id;
+  uint64_t content_size;
+} lz4mi_frame_options;
+
+void lz4mi_frame_options_default(lz4mi_frame_options *o);
+
+/* Upper bound of lz4mi_frame_encode's output for n input bytes. */
+size_t lz4mi_frame_bound(size_t n, const lz4mi_frame_options *o);
+
+/* lz4FrameEncodeWithOptions  lib/dart_lz4.dart:110-117 ->
+ * lz4FrameEncodeBytesWithOptions lib/src/frame/lz4_frame_encoder.dart:105-274.
+ * Host buffers.  A contentSize that differs from n is reported
+ * (LZ4MI_FORMAT_CONTENT_SIZE_ARG) after the frame has been produced (:269-271). */
+int32_t lz4mi_frame_encode(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
+                           const lz4mi_frame_options *o, const uint8_t *dict, size_t dict_len,
+                           uint8_t *dst, size_t cap, size_t *out_len);
+
+/* Same, device-resident source and destination (independent blocks only).
+ * first_block_index/emit_header/emit_trailer let N ranks each encode a
+ * contiguous block range of one frame: rank r passes its shard, gets per-block
+ * stored sizes in d_stored_sizes, and after the sizes have been exchanged
+ * calls lz4mi_frame_assemble_shard with its absolute base offset. */
+int32_t lz4mi_frame_encode_device(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
+                                  const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                  uint32_t dict_len, uint8_t *d_dst, uint64_t cap,
+                                  uint64_t *out_len);
+
+/* Multi-GPU frame assembly, step 1: compress this rank's blocks (device
+ * resident) and report each block's record size in the frame:
+ * 4 + stored_len (+4 with block checksums), where stored_len follows the
+ * compressed-iff-smaller rule (lib/src/frame/lz4_frame_encoder.dart:235).
+ * The compressed payloads stay in the context's scratch until step 2. */
+int32_t lz4mi_frame_shard_compress(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
+                                   const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                   uint32_t dict_len, uint32_t *d_record_sizes,
+                                   uint32_t *nblocks_out);
+
+/* Step 2: after the record sizes of all ranks have been all-gathered and
+ * prefix-summed by the caller, write this rank's block records contiguously
+ * into d_dst (the rank's window of the frame), i.e. bytes
+ * [shard_base, shard_base + sum(record sizes)) of the frame body.
+ * d_record_offsets[b] = offset of block b's record relative to d_dst. */
+int32_t lz4mi_frame_shard_write(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
+                                const lz4mi_frame_options *o, const uint64_t *d_record_offsets,
+                                uint8_t *d_dst, uint64_t cap);
+
+/* Frame header bytes (magic..HC) and trailer (end mark [+ content checksum]).
+ * lib/src/frame/lz4_frame_encoder.dart:110-144 and :263-267. Host buffers. */
+int32_t lz4mi_frame_header(const lz4mi_frame_options *o, uint8_t *dst, size_t cap, size_t *out_len);
+
+/* One frame or skippable frame per call, so the caller's loop can run the
+ * Lz4DictionaryResolver callback between header parse and block decode
+ * (_decodeNextFrameOrSkippable lib/src/frame/lz4_frame_decoder.dart:52-76,
+ * resolver :225-236).  Host buffers.
+ *
+ * max_out < 0: no limit ("maxOutputBytes: null"); otherwise the remaining
+ * budget for this frame (:158-164).  dict/dict_len: the dictionary to use
+ * (dict == NULL and have_dict == 0: none).  If the frame carries a dictId and
+ * dict_state is 0 ("not resolved yet"), returns LZ4MI_NEED_DICT with
+ * *dict_id_needed set and *consumed = 0; the caller resolves and calls again
+ * with dict_state 1 (resolved; dict may be empty), 2 (no resolver supplied)
+ * or 3 (resolver returned null). */
+int32_t lz4mi_frame_decode_next(lz4mi_ctx *ctx, const uint8_t *src, size_t len, size_t *consumed,
+                                const uint8_t *dict, size_t dict_len, int32_t dict_state,
+                                int32_t have_prev_dict, int64_t max_out, uint8_t *dst, size_t cap,
+                                size_t *out_len, uint32_t *dict_id_needed);
+
+/* Size of the output lz4mi_frame_decode_next will need for the next frame:
+ * parses only the header and walks the block size words on the host.
+ * Returns an upper bound (blocks * blockMaxSize), or the contentSize field. */
+int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

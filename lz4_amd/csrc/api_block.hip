@@ -1,0 +1,383 @@
+// liblz4mi: context, block-level entry points (single block on host buffers and
+// device-resident batches) and xxHash32.  See include/lz4mi.h for the contract.
+#include "api_common.h"
+
+using namespace lz4mi;
+
+// ------------------------------------------------------------------ status
+
+extern "C" const char *lz4mi_status_type(int32_t s) {
+  if (s == LZ4MI_OK) return "OK";
+  if (s >= 1 && s < 10) return "Lz4FormatException";
+  if (s >= 10 && s < 30) return "Lz4CorruptDataException";
+  if (s == LZ4MI_LIMIT) return "Lz4OutputLimitException";
+  if (s >= 40 && s < 50) return "Lz4UnsupportedFeatureException";
+  if (s == LZ4MI_DICT_NOT_FOUND) return "Lz4Exception";
+  if (s == LZ4MI_RANGE) return "RangeError";
+  return "Lz4BackendError";
+}
+
+extern "C" const char *lz4mi_status_message(int32_t s) {
+  switch (s) {
+    case LZ4MI_OK: return "";
+    case LZ4MI_FORMAT_EOF: return "Unexpected end of input";
+    case LZ4MI_FORMAT_MAGIC: return "Invalid LZ4 frame magic number";
+    case LZ4MI_FORMAT_FLG_RESERVED: return "Reserved FLG bit is set";
+    case LZ4MI_FORMAT_BD_RESERVED: return "Reserved BD bits are set";
+    case LZ4MI_FORMAT_BLOCK_MAX: return "Invalid block maximum size";
+    case LZ4MI_FORMAT_INT_OVERFLOW: return "Integer overflow";
+    case LZ4MI_FORMAT_CONTENT_SIZE_ARG: return "contentSize does not match src length";
+    case LZ4MI_CORRUPT_LITERAL: return "Literal length exceeds output size";
+    case LZ4MI_CORRUPT_MATCH: return "Match length exceeds output size";
+    case LZ4MI_CORRUPT_TRAILING: return "Trailing bytes after end of block";
+    case LZ4MI_CORRUPT_DISTANCE: return "Invalid match distance";
+    case LZ4MI_CORRUPT_HEADER_CK: return "Header checksum mismatch";
+    case LZ4MI_CORRUPT_BLOCK_SIZE: return "Block size exceeds maximum";
+    case LZ4MI_CORRUPT_BLOCK_CK: return "Block checksum mismatch";
+    case LZ4MI_CORRUPT_CONTENT_CK: return "Content checksum mismatch";
+    case LZ4MI_CORRUPT_CONTENT_SIZE: return "Content size mismatch";
+    case LZ4MI_CORRUPT_LEGACY_SIZE: return "Invalid legacy block size";
+    case LZ4MI_CORRUPT_LEGACY_NOT_FULL: return "Legacy block is not full";
+    case LZ4MI_LIMIT: return "Output limit exceeded";
+    case LZ4MI_UNSUPPORTED_VERSION: return "Unsupported LZ4 frame version";
+    case LZ4MI_UNSUPPORTED_DICT: return "Dictionary ID present but no dictionary resolver provided";
+    case LZ4MI_DICT_NOT_FOUND: return "Dictionary not found for ID: ";
+    case LZ4MI_RANGE: return "Invalid argument";
+    case LZ4MI_BACKEND: return "HIP backend failure";
+    case LZ4MI_DST_TOO_SMALL: return "destination buffer too small";
+    case LZ4MI_NEED_DICT: return "dictionary required";
+    case LZ4MI_UNSUPPORTED_HERE: return "not supported by the device path";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int32_t lz4mi_version(void) { return 10000; }
+extern "C" size_t lz4mi_compress_bound(size_t n) { return bound(n); }
+
+// ----------------------------------------------------------------- context
+
+enum { kCounterDecode = 0, kCounterEncode = 1, kCounterHc = 2, kNumCounters = 16 };
+
+extern "C" int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **out) {
+  if (!out) return LZ4MI_RANGE;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LZ4MI_BACKEND;
+  lz4mi_ctx *c = new lz4mi_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return LZ4MI_BACKEND; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->cu_count = prop.multiProcessorCount;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LZ4MI_BACKEND; }
+    c->own_stream = true;
+  }
+  if (hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)) != hipSuccess) {
+    lz4mi_ctx_destroy(c);
+    return LZ4MI_BACKEND;
+  }
+  uint32_t wpc = 16;  // resident encoder wavefronts per CU (one 256 KiB table each)
+  if (const char *e = getenv("LZ4MI_ENC_WAVES_PER_CU")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 32) wpc = (uint32_t)v;
+  }
+  c->max_slots = (uint32_t)c->cu_count * wpc;
+  *out = c;
+  return LZ4MI_OK;
+}
+
+extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf *bufs[] = {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
+                    &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
+                    &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
+                    &c->hc_chain};
+  for (DevBuf *b : bufs) b->release();
+  if (c->d_counters) (void)hipFree(c->d_counters);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int32_t lz4mi_ctx_synchronize(lz4mi_ctx *c) {
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  return LZ4MI_OK;
+}
+
+extern "C" const char *lz4mi_last_backend_error(lz4mi_ctx *c) { return c ? c->err.c_str() : ""; }
+
+namespace lz4mi {
+
+int32_t pin_reserve(lz4mi_ctx *c, size_t n) {
+  if (n <= c->h_pin_cap) return LZ4MI_OK;
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  c->h_pin = nullptr;
+  c->h_pin_cap = 0;
+  size_t want = round_up(n + n / 4, 4096);
+  LZ4MI_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
+  c->h_pin_cap = want;
+  return LZ4MI_OK;
+}
+
+static uint32_t wave_grid(lz4mi_ctx *c, uint32_t nblocks, uint32_t waves_per_cu) {
+  uint32_t groups = (nblocks + 3) / 4;
+  uint32_t cap = (uint32_t)c->cu_count * waves_per_cu / 4;
+  return groups < cap ? (groups ? groups : 1) : cap;
+}
+
+static int32_t ensure_slots(lz4mi_ctx *c, uint32_t want) {
+  if (want > c->max_slots) want = c->max_slots;
+  want = (uint32_t)round_up(want, 4);
+  if (want <= c->nslots) return LZ4MI_OK;
+  // growing restarts every slot at generation 0 over a zeroed table
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  LZ4MI_HIP(c, c->tables.ensure((size_t)want * kHashEntries * sizeof(uint32_t)));
+  LZ4MI_HIP(c, c->slot_gen.ensure((size_t)want * sizeof(uint32_t)));
+  LZ4MI_HIP(c, hipMemsetAsync(c->tables.p, 0, (size_t)want * kHashEntries * sizeof(uint32_t), c->stream));
+  LZ4MI_HIP(c, hipMemsetAsync(c->slot_gen.p, 0, (size_t)want * sizeof(uint32_t), c->stream));
+  c->nslots = want;
+  return LZ4MI_OK;
+}
+
+int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a_in, int64_t acceleration) {
+  if (acceleration < 1) return LZ4MI_RANGE;  // lz4_block_encoder.dart:41-43
+  if (a_in.nblocks == 0) return LZ4MI_OK;
+  BatchArgs a = a_in;
+  if (a.dict == nullptr) a.dict_len = 0;
+  if (a.dict_len > 65535) {  // encoder keeps the last 65535 dictionary bytes (:50-61)
+    a.dict += a.dict_len - 65535;
+    a.dict_len = 65535;
+  }
+  int32_t st = ensure_slots(c, a.nblocks);
+  if (st) return st;
+  EncodeScratch sc;
+  sc.tables = c->tables.as<uint32_t>();
+  sc.slot_gen = c->slot_gen.as<uint32_t>();
+  sc.nslots = c->nslots;
+  sc.dict_table = nullptr;
+  if (a.dict_len) {
+    LZ4MI_HIP(c, c->dict_table.ensure(kHashEntries * sizeof(uint32_t)));
+    sc.dict_table = c->dict_table.as<uint32_t>();
+    launch_dict_prime(a.dict, a.dict_len, sc.dict_table, c->stream);
+  }
+  uint32_t sh = acceleration > 31 ? 31u : (uint32_t)acceleration;  // offsets stay below 2^31
+  uint32_t *counter = c->d_counters + kCounterEncode;
+  LZ4MI_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
+  uint32_t grid = (a.nblocks + 3) / 4;
+  if (grid > c->nslots / 4) grid = c->nslots / 4;
+  launch_encode_fast(a, sh, sc, counter, grid, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
+  if (a_in.nblocks == 0) return LZ4MI_OK;
+  BatchArgs a = a_in;
+  if (a.dict == nullptr) a.dict_len = 0;
+  if (a.dict_len > 65536) {  // decoder keeps the last 65536 bytes (lz4_frame_decoder.dart:278-282)
+    a.dict += a.dict_len - 65536;
+    a.dict_len = 65536;
+  }
+  uint32_t *counter = c->d_counters + kCounterDecode;
+  LZ4MI_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
+  launch_decode(a, strict, counter, wave_grid(c, a.nblocks, 32), c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+static void to_args(const lz4mi_batch *b, BatchArgs &a) {
+  a.src = b->d_src;
+  a.src_off = b->d_src_off;
+  a.src_len = b->d_src_len;
+  a.src_stride = b->src_stride;
+  a.src_len_uniform = b->src_len_uniform;
+  a.src_total = b->src_total;
+  a.dst = b->d_dst;
+  a.dst_off = b->d_dst_off;
+  a.dst_stride = b->dst_stride;
+  a.dst_cap = b->d_dst_cap;
+  a.dst_cap_uniform = b->dst_cap_uniform;
+  a.dict = b->d_dict;
+  a.dict_len = b->d_dict ? b->dict_len : 0;
+  a.nblocks = b->nblocks;
+  a.out_len = b->d_out_len;
+  a.status = b->d_status;
+}
+
+}  // namespace lz4mi
+
+// ------------------------------------------------------------ batch entry points
+
+extern "C" int32_t lz4mi_compress_fast_batch(lz4mi_ctx *c, const lz4mi_batch *b, int64_t acceleration) {
+  if (!c || !b) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  BatchArgs a;
+  to_args(b, a);
+  return run_compress_fast(c, a, acceleration);
+}
+
+extern "C" int32_t lz4mi_compress_hc_batch(lz4mi_ctx *c, const lz4mi_batch *b, int64_t depth) {
+  if (!c || !b) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  BatchArgs a;
+  to_args(b, a);
+  return run_compress_hc(c, a, depth);
+}
+
+extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, int32_t strict) {
+  if (!c || !b) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  BatchArgs a;
+  to_args(b, a);
+  return run_decompress(c, a, strict != 0);
+}
+
+extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_t *d_hash) {
+  if (!c || !b || !d_hash) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  BatchArgs a;
+  to_args(b, a);
+  launch_xxh32_batch(a, d_hash, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_xxh32_device(lz4mi_ctx *c, const uint8_t *d_data, uint64_t len, uint32_t seed,
+                                      uint32_t *d_out) {
+  if (!c || !d_out) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  launch_xxh32_serial(d_data, len, seed, d_out, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+// ------------------------------------------------- single block, host buffers
+
+namespace {
+
+struct OneResult {
+  uint32_t out_len;
+  int32_t status;
+};
+
+// Runs one block through a batch kernel: src (+dict) up, result down.
+int32_t one_block(lz4mi_ctx *c, const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
+                  size_t dev_out_bytes, uint32_t cap_field, int kind, int64_t param, OneResult *res) {
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, c->in.ensure(n + 16));
+  LZ4MI_HIP(c, c->out.ensure(dev_out_bytes + 16));
+  LZ4MI_HIP(c, c->comp_len.ensure(16));
+  LZ4MI_HIP(c, c->status.ensure(16));
+  int32_t st = pin_reserve(c, 64);
+  if (st) return st;
+  if (n) LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, src, n, hipMemcpyHostToDevice, c->stream));
+  if (dict_len) {
+    LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->dictbuf.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+  }
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = c->in.as<uint8_t>();
+  a.src_len_uniform = (uint32_t)n;
+  a.src_total = n;
+  a.dst = c->out.as<uint8_t>();
+  a.dst_cap_uniform = cap_field;
+  a.dict = dict_len ? c->dictbuf.as<uint8_t>() : nullptr;
+  a.dict_len = (uint32_t)dict_len;
+  a.nblocks = 1;
+  a.out_len = c->comp_len.as<uint32_t>();
+  a.status = c->status.as<int32_t>();
+  if (kind == 0) st = run_compress_fast(c, a, param);
+  else if (kind == 1) st = run_compress_hc(c, a, param);
+  else st = run_decompress(c, a, kind == 2);
+  if (st) return st;
+  uint32_t *h = (uint32_t *)c->h_pin;
+  LZ4MI_HIP(c, hipMemcpyAsync(h, a.out_len, 4, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipMemcpyAsync(h + 1, a.status, 4, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  res->out_len = h[0];
+  res->status = (int32_t)h[1];
+  return LZ4MI_OK;
+}
+
+int32_t compress_one(lz4mi_ctx *c, int kind, const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
+                     int64_t param, uint8_t *dst, size_t cap, size_t *out_len) {
+  if (!c) return LZ4MI_RANGE;
+  if (out_len) *out_len = 0;
+  if (param < 1) return LZ4MI_RANGE;
+  if (n == 0) return LZ4MI_OK;  // lz4_block_encoder.dart:45-48
+  if (n > kPosMask - 65536u - 8u) return LZ4MI_UNSUPPORTED_HERE;  // table positions are 24-bit
+  if (!dict) dict_len = 0;
+  OneResult r;
+  size_t b = bound(n);
+  int32_t st = one_block(c, src, n, dict, dict_len, b, (uint32_t)b, kind, param, &r);
+  if (st) return st;
+  if (r.status) return r.status;
+  if (r.out_len > cap) return LZ4MI_DST_TOO_SMALL;
+  LZ4MI_HIP(c, hipMemcpy(dst, c->out.p, r.out_len, hipMemcpyDeviceToHost));
+  if (out_len) *out_len = r.out_len;
+  return LZ4MI_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t lz4mi_block_compress_fast(lz4mi_ctx *c, const uint8_t *src, size_t n, const uint8_t *dict,
+                                             size_t dict_len, int64_t acceleration, uint8_t *dst, size_t cap,
+                                             size_t *out_len) {
+  return compress_one(c, 0, src, n, dict, dict_len, acceleration, dst, cap, out_len);
+}
+
+extern "C" int32_t lz4mi_block_compress_hc(lz4mi_ctx *c, const uint8_t *src, size_t n, const uint8_t *dict,
+                                           size_t dict_len, int64_t depth, uint8_t *dst, size_t cap,
+                                           size_t *out_len) {
+  return compress_one(c, 1, src, n, dict, dict_len, depth, dst, cap, out_len);
+}
+
+extern "C" int32_t lz4mi_block_decompress(lz4mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst,
+                                          int64_t decompressed_size) {
+  if (!c) return LZ4MI_RANGE;
+  if (decompressed_size < 0) return LZ4MI_RANGE;  // lz4_block_decoder.dart:11-13
+  if (decompressed_size > 0x7fffffff || n > 0x7fffffff) return LZ4MI_UNSUPPORTED_HERE;
+  OneResult r;
+  int32_t st = one_block(c, src, n, nullptr, 0, (size_t)decompressed_size, (uint32_t)decompressed_size, 2, 0, &r);
+  if (st) return st;
+  if (r.status) return r.status;
+  if (r.out_len) LZ4MI_HIP(c, hipMemcpy(dst, c->out.p, r.out_len, hipMemcpyDeviceToHost));
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_block_decompress_into(lz4mi_ctx *c, const uint8_t *src, size_t n, uint8_t *dst,
+                                               size_t prefix_len, size_t max_len, size_t *out_len) {
+  if (!c) return LZ4MI_RANGE;
+  if (out_len) *out_len = prefix_len;
+  if (max_len < prefix_len) return LZ4MI_LIMIT;
+  if (max_len - prefix_len > 0x7fffffff || n > 0x7fffffff || prefix_len > 0x7fffffff) return LZ4MI_UNSUPPORTED_HERE;
+  OneResult r;
+  size_t room = max_len - prefix_len;
+  int32_t st = one_block(c, src, n, dst, prefix_len, room, (uint32_t)room, 3, 0, &r);
+  if (st) return st;
+  if (r.out_len) LZ4MI_HIP(c, hipMemcpy(dst + prefix_len, c->out.p, r.out_len, hipMemcpyDeviceToHost));
+  if (out_len) *out_len = prefix_len + r.out_len;
+  return r.status;
+}
+
+extern "C" int32_t lz4mi_xxh32(lz4mi_ctx *c, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out) {
+  if (!c || !out) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, c->in.ensure(len + 16));
+  LZ4MI_HIP(c, c->words.ensure(64));
+  int32_t st = pin_reserve(c, 64);
+  if (st) return st;
+  if (len) LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, data, len, hipMemcpyHostToDevice, c->stream));
+  launch_xxh32_serial(c->in.as<uint8_t>(), len, seed, c->words.as<uint32_t>(), c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  LZ4MI_HIP(c, hipMemcpyAsync(c->h_pin, c->words.p, 4, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  *out = *(uint32_t *)c->h_pin;
+  return LZ4MI_OK;
+}

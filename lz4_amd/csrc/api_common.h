@@ -1,0 +1,104 @@
+// Context and host-side helpers of liblz4mi (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/lz4mi.h"
+#include "frame_kernels.h"
+#include "kernels.h"
+
+namespace lz4mi {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t n) {
+    if (n <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T *as() const { return (T *)p; }
+};
+
+}  // namespace lz4mi
+
+struct lz4mi_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int cu_count = 256;
+  std::string err;
+
+  uint32_t *d_counters = nullptr;  // work-queue heads, one per launch kind
+
+  // fast/HC encoder hash tables: one 65536-entry slot per resident wavefront
+  lz4mi::DevBuf tables, slot_gen, dict_table, dict_copy;
+  uint32_t nslots = 0;
+  uint32_t max_slots = 0;
+
+  // staging for the host-buffer entry points
+  lz4mi::DevBuf in, out, aux, dictbuf;
+  // per-block bookkeeping
+  lz4mi::DevBuf comp, comp_len, status, stored_word, payload_addr, payload_len, record_size, rec_off,
+      hashes, words, total;
+  // HC encoder chains
+  lz4mi::DevBuf hc_chain;
+
+  // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
+  uint32_t shard_blocks = 0;
+  int shard_block_checksum = 0;
+
+  void *h_pin = nullptr;  // pinned host scratch for small read-backs
+  size_t h_pin_cap = 0;
+};
+
+namespace lz4mi {
+
+inline int32_t fail(lz4mi_ctx *c, hipError_t e, const char *what) {
+  c->err = std::string(what) + ": " + hipGetErrorString(e);
+  return LZ4MI_BACKEND;
+}
+
+#define LZ4MI_HIP(c, call)                                   \
+  do {                                                       \
+    hipError_t e_ = (call);                                  \
+    if (e_ != hipSuccess) return ::lz4mi::fail((c), e_, #call); \
+  } while (0)
+
+inline size_t block_max_bytes(int id) {  // lib/src/frame/lz4_frame_options.dart:117-128
+  switch (id) {
+    case 4: return 64u << 10;
+    case 5: return 256u << 10;
+    case 6: return 1u << 20;
+    case 7: return 4u << 20;
+    default: return 0;
+  }
+}
+
+inline size_t bound(size_t n) { return n + n / 255 + 16; }
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// batch entry points used by both the public batch API and the frame layer
+int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a, int64_t acceleration);
+int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a, int64_t depth);
+int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict);
+int32_t pin_reserve(lz4mi_ctx *c, size_t n);
+
+}  // namespace lz4mi

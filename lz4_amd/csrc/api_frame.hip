@@ -1,0 +1,665 @@
+// liblz4mi: frame layer.  Host code parses/validates headers and walks the block
+// size words; every per-block loop body of the reference's dispatchers
+// (lib/src/frame/lz4_frame_encoder.dart:154-261, lz4_frame_decoder.dart:238-304)
+// runs as batched kernels over all blocks of the frame.
+#include "api_common.h"
+
+using namespace lz4mi;
+
+namespace {
+
+const uint32_t kFrameMagic = 0x184D2204u, kSkippableBase = 0x184D2A50u, kLegacyMagic = 0x184C2102u;
+
+// xxHash32 of a frame descriptor (2..14 bytes, always < 16 so only the short tail
+// path of lib/src/xxhash/xxh32.dart:215-239 applies).  Host-side because the header is
+// built and validated on the host; bulk hashing runs on the GPU (xxh32_kernel.hip).
+uint32_t descriptor_hash(const uint8_t *p, size_t len) {
+  auto rotl = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+  uint32_t h = 0x165667B1u + (uint32_t)len;
+  size_t k = 0;
+  for (; k + 4 <= len; k += 4) {
+    uint32_t w = (uint32_t)p[k] | ((uint32_t)p[k + 1] << 8) | ((uint32_t)p[k + 2] << 16) | ((uint32_t)p[k + 3] << 24);
+    h = rotl(h + w * 0xC2B2AE3Du, 17) * 0x27D4EB2Fu;
+  }
+  for (; k < len; k++) h = rotl(h + p[k] * 0x165667B1u, 11) * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+
+inline uint32_t rd32(const uint8_t *p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+inline void wr32(uint8_t *p, uint32_t v) {
+  p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+int32_t validate_options(const lz4mi_frame_options *o) {
+  if (!o) return LZ4MI_RANGE;
+  if (o->acceleration < 1) return LZ4MI_RANGE;        // lz4_frame_options.dart:89-91
+  if (!block_max_bytes(o->block_size_id)) return LZ4MI_RANGE;
+  if (o->compression == 1 && o->hc_max_search_depth < 1) return LZ4MI_RANGE;
+  if (o->has_content_size && (o->content_size >> 63)) return LZ4MI_RANGE;  // :92-95
+  return LZ4MI_OK;
+}
+
+size_t build_header(const lz4mi_frame_options *o, uint8_t *h) {  // lz4_frame_encoder.dart:110-144
+  wr32(h, kFrameMagic);
+  h[4] = (uint8_t)((1u << 6) | ((o->block_independence ? 1u : 0u) << 5) | ((o->block_checksum ? 1u : 0u) << 4) |
+                   ((o->has_content_size ? 1u : 0u) << 3) | ((o->content_checksum ? 1u : 0u) << 2) |
+                   (o->has_dict_id ? 1u : 0u));
+  h[5] = (uint8_t)(((uint32_t)o->block_size_id & 7u) << 4);
+  size_t n = 6;
+  if (o->has_content_size) {
+    wr32(h + n, (uint32_t)(o->content_size & 0xFFFFFFFFu));
+    wr32(h + n + 4, (uint32_t)(o->content_size >> 32));
+    n += 8;
+  }
+  if (o->has_dict_id) {
+    wr32(h + n, o->dict_id);
+    n += 4;
+  }
+  h[n] = (uint8_t)((descriptor_hash(h + 4, n - 4) >> 8) & 0xff);
+  return n + 1;
+}
+
+// Compresses every block of a device-resident range and plans its frame record.
+int32_t shard_compress(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4mi_frame_options *o,
+                       const uint8_t *d_dict, uint32_t dict_len, uint32_t *nblocks_out) {
+  const size_t bmax = block_max_bytes(o->block_size_id);
+  if (n / bmax > 0x7ffffff0u) return LZ4MI_RANGE;
+  const uint32_t nb = (uint32_t)((n + bmax - 1) / bmax);
+  *nblocks_out = nb;
+  c->shard_blocks = nb;
+  c->shard_block_checksum = o->block_checksum;
+  if (nb == 0) return LZ4MI_OK;
+  const size_t blk = n < bmax ? (size_t)n : bmax;
+  const size_t stride = round_up(bound(blk), 64);
+  LZ4MI_HIP(c, c->comp.ensure((size_t)nb * stride));
+  LZ4MI_HIP(c, c->comp_len.ensure((size_t)nb * 4));
+  LZ4MI_HIP(c, c->status.ensure((size_t)nb * 4));
+  LZ4MI_HIP(c, c->stored_word.ensure((size_t)nb * 4));
+  LZ4MI_HIP(c, c->payload_addr.ensure((size_t)nb * 8));
+  LZ4MI_HIP(c, c->payload_len.ensure((size_t)nb * 4));
+  LZ4MI_HIP(c, c->record_size.ensure((size_t)nb * 4));
+  LZ4MI_HIP(c, c->hashes.ensure((size_t)nb * 4));
+
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = d_src;
+  a.src_stride = bmax;
+  a.src_len_uniform = (uint32_t)bmax;
+  a.src_total = n;
+  a.dst = c->comp.as<uint8_t>();
+  a.dst_stride = stride;
+  a.dst_cap_uniform = (uint32_t)stride;
+  a.dict = d_dict;
+  a.dict_len = d_dict ? dict_len : 0;
+  a.nblocks = nb;
+  a.out_len = c->comp_len.as<uint32_t>();
+  a.status = c->status.as<int32_t>();
+  int32_t st = o->compression == 0 ? run_compress_fast(c, a, o->acceleration)
+                                   : run_compress_hc(c, a, o->hc_max_search_depth);
+  if (st) return st;
+
+  FramePlanArgs p;
+  p.src = d_src;
+  p.src_total = n;
+  p.block_max = (uint32_t)bmax;
+  p.comp = c->comp.as<uint8_t>();
+  p.comp_stride = stride;
+  p.comp_len = c->comp_len.as<uint32_t>();
+  p.nblocks = nb;
+  p.block_checksum = o->block_checksum;
+  p.stored_word = c->stored_word.as<uint32_t>();
+  p.payload_addr = c->payload_addr.as<uint64_t>();
+  p.payload_len = c->payload_len.as<uint32_t>();
+  p.record_size = c->record_size.as<uint32_t>();
+  launch_frame_plan(p, c->stream);
+  if (o->block_checksum) {  // checksum of the payload as stored (:242-257)
+    BatchArgs h;
+    memset(&h, 0, sizeof h);
+    h.src = nullptr;  // absolute addresses
+    h.src_off = c->payload_addr.as<uint64_t>();
+    h.src_len = c->payload_len.as<uint32_t>();
+    h.nblocks = nb;
+    launch_xxh32_batch(h, c->hashes.as<uint32_t>(), c->stream);
+  }
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+int32_t shard_write(lz4mi_ctx *c, const uint64_t *d_rec_off, uint8_t *d_dst) {
+  const uint32_t nb = c->shard_blocks;
+  if (!nb) return LZ4MI_OK;
+  launch_frame_words(d_dst, d_rec_off, c->stored_word.as<uint32_t>(), c->payload_len.as<uint32_t>(),
+                     c->shard_block_checksum ? c->hashes.as<uint32_t>() : nullptr, nb, c->stream);
+  launch_seg_copy(c->payload_addr.as<uint64_t>(), d_dst, d_rec_off, 4, c->payload_len.as<uint32_t>(), nb,
+                  c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+}  // namespace
+
+extern "C" void lz4mi_frame_options_default(lz4mi_frame_options *o) {  // lz4_frame_options.dart:78-88
+  memset(o, 0, sizeof *o);
+  o->block_size_id = 7;
+  o->block_independence = 1;
+  o->acceleration = 1;
+  o->hc_max_search_depth = 64;
+}
+
+extern "C" size_t lz4mi_frame_bound(size_t n, const lz4mi_frame_options *o) {
+  size_t bmax = block_max_bytes(o ? o->block_size_id : 7);
+  if (!bmax) bmax = 4u << 20;
+  size_t nb = (n + bmax - 1) / bmax;
+  return 19 + nb * 8 + n + 8;  // a block is never stored larger than its source (:235)
+}
+
+extern "C" int32_t lz4mi_frame_header(const lz4mi_frame_options *o, uint8_t *dst, size_t cap, size_t *out_len) {
+  int32_t st = validate_options(o);
+  if (st) return st;
+  uint8_t h[32];
+  size_t n = build_header(o, h);
+  if (n > cap) return LZ4MI_DST_TOO_SMALL;
+  memcpy(dst, h, n);
+  if (out_len) *out_len = n;
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_frame_shard_compress(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
+                                              const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                              uint32_t dict_len, uint32_t *d_record_sizes, uint32_t *nblocks_out) {
+  if (!c || !nblocks_out) return LZ4MI_RANGE;
+  int32_t st = validate_options(o);
+  if (st) return st;
+  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  st = shard_compress(c, d_src, n, o, d_dict, dict_len, nblocks_out);
+  if (st) return st;
+  if (d_record_sizes && *nblocks_out)
+    LZ4MI_HIP(c, hipMemcpyAsync(d_record_sizes, c->record_size.p, (size_t)*nblocks_out * 4,
+                                hipMemcpyDeviceToDevice, c->stream));
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_frame_shard_write(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
+                                           const lz4mi_frame_options *o, const uint64_t *d_record_offsets,
+                                           uint8_t *d_dst, uint64_t cap) {
+  (void)d_src; (void)n; (void)o; (void)cap;
+  if (!c || !d_record_offsets || !d_dst) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  return shard_write(c, d_record_offsets, d_dst);
+}
+
+extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
+                                             const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                             uint32_t dict_len, uint8_t *d_dst, uint64_t cap, uint64_t *out_len) {
+  if (!c) return LZ4MI_RANGE;
+  int32_t st = validate_options(o);
+  if (st) return st;
+  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  if (cap < lz4mi_frame_bound((size_t)n, o)) return LZ4MI_DST_TOO_SMALL;
+  uint8_t hdr[32];
+  const size_t hlen = build_header(o, hdr);
+  st = pin_reserve(c, 256);
+  if (st) return st;
+  memcpy(c->h_pin, hdr, hlen);
+  LZ4MI_HIP(c, hipMemcpyAsync(d_dst, c->h_pin, hlen, hipMemcpyHostToDevice, c->stream));
+  uint32_t nb = 0;
+  st = shard_compress(c, d_src, n, o, d_dict, dict_len, &nb);
+  if (st) return st;
+  LZ4MI_HIP(c, c->rec_off.ensure((size_t)(nb + 1) * 8));
+  LZ4MI_HIP(c, c->total.ensure(64));
+  LZ4MI_HIP(c, c->words.ensure(64));
+  launch_scan_sizes(c->record_size.as<uint32_t>(), nb, hlen, c->rec_off.as<uint64_t>(), c->total.as<uint64_t>(),
+                    c->stream);
+  st = shard_write(c, c->rec_off.as<uint64_t>(), d_dst);
+  if (st) return st;
+  if (o->content_checksum)  // Xxh32 over all uncompressed content (:148,163,266)
+    launch_xxh32_serial(d_src, n, 0, c->words.as<uint32_t>(), c->stream);
+  // end mark (:263) [+ content checksum] behind the last record
+  uint64_t *h_total = (uint64_t *)((uint8_t *)c->h_pin + 128);
+  LZ4MI_HIP(c, hipMemcpyAsync(h_total, c->total.p, 8, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  const uint64_t body_end = *h_total;
+  launch_put_words(d_dst + body_end, c->words.as<uint32_t>(), o->content_checksum ? 1 : 0, true, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  if (out_len) *out_len = body_end + 4 + (o->content_checksum ? 4 : 0);
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n, const lz4mi_frame_options *o,
+                                      const uint8_t *dict, size_t dict_len, uint8_t *dst, size_t cap,
+                                      size_t *out_len) {
+  if (!c) return LZ4MI_RANGE;
+  if (out_len) *out_len = 0;
+  int32_t st = validate_options(o);
+  if (st) return st;
+  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  const size_t fb = lz4mi_frame_bound(n, o);
+  LZ4MI_HIP(c, c->in.ensure(n + 16));
+  LZ4MI_HIP(c, c->out.ensure(fb + 16));
+  if (n) LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, src, n, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *d_dict = nullptr;
+  if (dict && dict_len) {
+    LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->dictbuf.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+    d_dict = c->dictbuf.as<uint8_t>();
+  } else {
+    dict_len = 0;
+  }
+  uint64_t total = 0;
+  st = lz4mi_frame_encode_device(c, c->in.as<uint8_t>(), n, o, d_dict, (uint32_t)dict_len, c->out.as<uint8_t>(),
+                                 fb, &total);
+  if (st) return st;
+  if (total > cap) return LZ4MI_DST_TOO_SMALL;
+  LZ4MI_HIP(c, hipMemcpyAsync(dst, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  if (out_len) *out_len = total;
+  // raised after all the work, like the reference (:269-271)
+  if (o->has_content_size && (uint64_t)n != o->content_size) return LZ4MI_FORMAT_CONTENT_SIZE_ARG;
+  return LZ4MI_OK;
+}
+
+// --------------------------------------------------------------- frame decode
+
+namespace {
+
+struct Blk {
+  uint64_t payload_off;  // relative to the frame's first byte handed to the device
+  uint32_t size;
+  uint32_t raw;
+  uint32_t has_ck;
+  uint32_t ck;
+};
+
+struct Header {
+  int indep, block_ck, has_size, content_ck, has_dict;
+  size_t bmax;
+  uint64_t content_size;
+  uint32_t dict_id;
+  size_t len;  // bytes after the magic, including HC
+};
+
+// Header parse + validation in the reference's order (lz4_frame_decoder.dart:166-223).
+int32_t parse_header(const uint8_t *p, size_t rem, Header *h) {
+  if (rem < 3) return LZ4MI_FORMAT_EOF;
+  uint32_t flg = p[0], bd = p[1];
+  if (((flg >> 6) & 3) != 1) return LZ4MI_UNSUPPORTED_VERSION;
+  h->indep = (flg >> 5) & 1;
+  h->block_ck = (flg >> 4) & 1;
+  h->has_size = (flg >> 3) & 1;
+  h->content_ck = (flg >> 2) & 1;
+  h->has_dict = flg & 1;
+  if ((flg >> 1) & 1) return LZ4MI_FORMAT_FLG_RESERVED;
+  if (bd & 0x8F) return LZ4MI_FORMAT_BD_RESERVED;
+  h->bmax = block_max_bytes((bd >> 4) & 7);
+  if (!h->bmax) return LZ4MI_FORMAT_BLOCK_MAX;
+  size_t off = 2;
+  h->content_size = 0;
+  if (h->has_size) {
+    if (rem - off < 8) return LZ4MI_FORMAT_EOF;
+    h->content_size = (uint64_t)rd32(p + off) | ((uint64_t)rd32(p + off + 4) << 32);
+    if (h->content_size >> 63) return LZ4MI_FORMAT_INT_OVERFLOW;  // byte_reader.dart:74-76
+    off += 8;
+  }
+  h->dict_id = 0;
+  if (h->has_dict) {
+    if (rem - off < 4) return LZ4MI_FORMAT_EOF;
+    h->dict_id = rd32(p + off);
+    off += 4;
+  }
+  if (rem - off < 1) return LZ4MI_FORMAT_EOF;
+  if (p[off] != ((descriptor_hash(p, off) >> 8) & 0xff)) return LZ4MI_CORRUPT_HEADER_CK;
+  h->len = off + 1;
+  return LZ4MI_OK;
+}
+
+// Decodes the collected blocks on the device and folds the per-block results in stream
+// order.  `region` = host bytes that contain every payload, uploaded once.
+// walk_err: structural error met while reading block blocks.size() (0 = none).
+int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, const std::vector<Blk> &blocks,
+                      size_t slot, bool indep, const uint8_t *dict, size_t dict_len, bool have_dict,
+                      int32_t walk_err, int64_t max_out, bool want_content_hash, bool legacy,
+                      bool legacy_last_has_next, uint8_t *dst,
+                      size_t cap, size_t *out_len, uint32_t *content_hash) {
+  const uint32_t nb = (uint32_t)blocks.size();
+  *out_len = 0;
+  if (nb == 0) {
+    if (walk_err) return walk_err;
+    if (want_content_hash) {
+      LZ4MI_HIP(c, c->words.ensure(64));
+      int32_t st = pin_reserve(c, 64);
+      if (st) return st;
+      launch_xxh32_serial(nullptr, 0, 0, c->words.as<uint32_t>(), c->stream);
+      LZ4MI_HIP(c, hipMemcpyAsync(c->h_pin, c->words.p, 4, hipMemcpyDeviceToHost, c->stream));
+      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+      *content_hash = *(uint32_t *)c->h_pin;
+    }
+    return LZ4MI_OK;
+  }
+  LZ4MI_HIP(c, c->in.ensure(region_len + 16));
+  LZ4MI_HIP(c, c->out.ensure((size_t)nb * slot + 16));
+  LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, region, region_len, hipMemcpyHostToDevice, c->stream));
+  const uint8_t *d_dict = nullptr;
+  if (have_dict && dict_len) {
+    LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->dictbuf.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
+    d_dict = c->dictbuf.as<uint8_t>();
+  }
+  // per-block arrays: [payload_off u64][payload_len u32][raw u32][dst_off u64][out_len u32][status i32][hash u32]
+  const size_t hb = (size_t)nb * (8 + 4 + 4 + 8 + 4 + 4 + 4);
+  int32_t st = pin_reserve(c, hb + 64);
+  if (st) return st;
+  uint64_t *h_poff = (uint64_t *)c->h_pin;
+  uint64_t *h_doff = h_poff + nb;
+  uint32_t *h_plen = (uint32_t *)(h_doff + nb);
+  uint32_t *h_raw = h_plen + nb;
+  uint32_t *h_olen = h_raw + nb;
+  int32_t *h_stat = (int32_t *)(h_olen + nb);
+  uint32_t *h_hash = (uint32_t *)(h_stat + nb);
+  LZ4MI_HIP(c, c->aux.ensure(hb + 64));
+  uint64_t *d_poff = c->aux.as<uint64_t>();
+  uint64_t *d_doff = d_poff + nb;
+  uint32_t *d_plen = (uint32_t *)(d_doff + nb);
+  uint32_t *d_raw = d_plen + nb;
+  uint32_t *d_olen = d_raw + nb;
+  int32_t *d_stat = (int32_t *)(d_olen + nb);
+  uint32_t *d_hash = (uint32_t *)(d_stat + nb);
+
+  bool any_ck = false;
+  for (uint32_t b = 0; b < nb; b++) {
+    h_poff[b] = blocks[b].payload_off;
+    h_doff[b] = (uint64_t)b * slot;
+    h_plen[b] = blocks[b].size;
+    h_raw[b] = blocks[b].raw;
+    any_ck |= blocks[b].has_ck != 0;
+  }
+  LZ4MI_HIP(c, hipMemcpyAsync(d_poff, h_poff, (size_t)nb * (8 + 8 + 4 + 4), hipMemcpyHostToDevice, c->stream));
+  LZ4MI_HIP(c, hipMemsetAsync(d_olen, 0, (size_t)nb * 8, c->stream));
+
+  if (indep) {
+    // compressed blocks through the batch decoder; stored blocks are plain copies.
+    // A stored block's src_len is zeroed for the decoder (decodes to nothing, status OK).
+    std::vector<uint64_t> raw_src, raw_dst;
+    std::vector<uint32_t> raw_len, dec_len(nb);
+    for (uint32_t b = 0; b < nb; b++) {
+      dec_len[b] = blocks[b].raw ? 0u : blocks[b].size;
+      if (blocks[b].raw) {
+        raw_src.push_back((uint64_t)(uintptr_t)(c->in.as<uint8_t>() + blocks[b].payload_off));
+        raw_dst.push_back((uint64_t)b * slot);
+        raw_len.push_back(blocks[b].size);
+      }
+    }
+    LZ4MI_HIP(c, c->payload_len.ensure((size_t)nb * 4));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->payload_len.p, dec_len.data(), (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
+    BatchArgs a;
+    memset(&a, 0, sizeof a);
+    a.src = c->in.as<uint8_t>();
+    a.src_off = d_poff;
+    a.src_len = c->payload_len.as<uint32_t>();
+    a.dst = c->out.as<uint8_t>();
+    a.dst_off = d_doff;
+    a.dst_cap_uniform = (uint32_t)slot;  // tmp ByteWriter(maxLength: blockMaxSize) :292
+    a.dict = d_dict;
+    a.dict_len = (uint32_t)(d_dict ? dict_len : 0);
+    a.nblocks = nb;
+    a.out_len = d_olen;
+    a.status = d_stat;
+    st = run_decompress(c, a, false);
+    if (st) return st;
+    if (!raw_src.empty()) {
+      const size_t nr = raw_src.size();
+      LZ4MI_HIP(c, c->payload_addr.ensure(nr * 8));
+      LZ4MI_HIP(c, c->rec_off.ensure(nr * 8));
+      LZ4MI_HIP(c, c->record_size.ensure(nr * 4));
+      LZ4MI_HIP(c, hipMemcpyAsync(c->payload_addr.p, raw_src.data(), nr * 8, hipMemcpyHostToDevice, c->stream));
+      LZ4MI_HIP(c, hipMemcpyAsync(c->rec_off.p, raw_dst.data(), nr * 8, hipMemcpyHostToDevice, c->stream));
+      LZ4MI_HIP(c, hipMemcpyAsync(c->record_size.p, raw_len.data(), nr * 4, hipMemcpyHostToDevice, c->stream));
+      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope below
+      launch_seg_copy(c->payload_addr.as<uint64_t>(), c->out.as<uint8_t>(), c->rec_off.as<uint64_t>(), 0,
+                      c->record_size.as<uint32_t>(), (uint32_t)nr, c->stream);
+    } else {
+      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+    }
+  } else {
+    ChainArgs ch;
+    ch.src = c->in.as<uint8_t>();
+    ch.payload_off = d_poff;
+    ch.payload_len = d_plen;
+    ch.raw = d_raw;
+    ch.nblocks = nb;
+    ch.block_max = (uint32_t)slot;
+    ch.dst = c->out.as<uint8_t>();
+    ch.dict = d_dict;
+    ch.dict_len = (uint32_t)(d_dict ? dict_len : 0);
+    ch.out_len = d_olen;
+    ch.status = d_stat;
+    launch_decode_chain(ch, c->stream);
+  }
+  if (any_ck) {  // block checksum of the payload as stored (:257-266)
+    BatchArgs h;
+    memset(&h, 0, sizeof h);
+    h.src = c->in.as<uint8_t>();
+    h.src_off = d_poff;
+    h.src_len = d_plen;
+    h.nblocks = nb;
+    launch_xxh32_batch(h, d_hash, c->stream);
+  }
+  LZ4MI_HIP(c, hipGetLastError());
+  LZ4MI_HIP(c, hipMemcpyAsync(h_olen, d_olen, (size_t)nb * 12, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+
+  // fold in stream order: first failing block decides
+  uint64_t produced = 0;
+  int32_t err = LZ4MI_OK;
+  bool contiguous = true;
+  uint32_t good = 0;
+  for (uint32_t b = 0; b < nb && !err; b++) {
+    const Blk &k = blocks[b];
+    if (k.has_ck && h_hash[b] != k.ck) { err = LZ4MI_CORRUPT_BLOCK_CK; break; }
+    uint32_t dsize = (k.raw && indep) ? k.size : h_olen[b];
+    if (!(k.raw && indep) && h_stat[b] != LZ4MI_OK) { err = h_stat[b]; break; }
+    if (!indep && !k.raw && dsize > slot) { err = LZ4MI_CORRUPT_BLOCK_SIZE; break; }  // :376-378
+    if (max_out >= 0 && produced + dsize > (uint64_t)max_out) { err = LZ4MI_LIMIT; break; }
+    if (produced + dsize > cap) { err = LZ4MI_DST_TOO_SMALL; break; }
+    if (indep && produced != (uint64_t)b * slot) contiguous = false;
+    h_olen[b] = dsize;
+    produced += dsize;
+    good = b + 1;
+    if (legacy && (b + 1 < nb || legacy_last_has_next) && dsize != slot) {  // :128-132
+      err = LZ4MI_CORRUPT_LEGACY_NOT_FULL;
+      break;
+    }
+  }
+  if (!err && walk_err) err = walk_err;
+  if (err) return err;
+
+  // gather the output
+  const uint8_t *d_frame_out = c->out.as<uint8_t>();
+  if (!contiguous) {  // short non-final blocks: compact the slots on the device
+    LZ4MI_HIP(c, c->comp.ensure((size_t)produced + 16));
+    std::vector<uint64_t> s_addr(good), d_off(good);
+    uint64_t run = 0;
+    for (uint32_t b = 0; b < good; b++) {
+      s_addr[b] = (uint64_t)(uintptr_t)(c->out.as<uint8_t>() + (uint64_t)b * slot);
+      d_off[b] = run;
+      run += h_olen[b];
+    }
+    LZ4MI_HIP(c, c->payload_addr.ensure((size_t)good * 8));
+    LZ4MI_HIP(c, c->rec_off.ensure((size_t)good * 8));
+    LZ4MI_HIP(c, c->record_size.ensure((size_t)good * 4));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->payload_addr.p, s_addr.data(), (size_t)good * 8, hipMemcpyHostToDevice, c->stream));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->rec_off.p, d_off.data(), (size_t)good * 8, hipMemcpyHostToDevice, c->stream));
+    LZ4MI_HIP(c, hipMemcpyAsync(c->record_size.p, h_olen, (size_t)good * 4, hipMemcpyHostToDevice, c->stream));
+    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+    launch_seg_copy(c->payload_addr.as<uint64_t>(), c->comp.as<uint8_t>(), c->rec_off.as<uint64_t>(), 0,
+                    c->record_size.as<uint32_t>(), good, c->stream);
+    d_frame_out = c->comp.as<uint8_t>();
+  }
+  if (want_content_hash) {  // xxh32(frameOut) :306-315
+    LZ4MI_HIP(c, c->words.ensure(64));
+    launch_xxh32_serial(d_frame_out, produced, 0, c->words.as<uint32_t>(), c->stream);
+    LZ4MI_HIP(c, hipMemcpyAsync((uint8_t *)c->h_pin + hb, c->words.p, 4, hipMemcpyDeviceToHost, c->stream));
+  }
+  if (produced) LZ4MI_HIP(c, hipMemcpyAsync(dst, d_frame_out, produced, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  if (want_content_hash) *content_hash = *(uint32_t *)((uint8_t *)c->h_pin + hb);
+  *out_len = produced;
+  return LZ4MI_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t lz4mi_frame_decode_next(lz4mi_ctx *c, const uint8_t *src, size_t len, size_t *consumed,
+                                           const uint8_t *dict, size_t dict_len, int32_t dict_state,
+                                           int32_t have_prev_dict, int64_t max_out, uint8_t *dst, size_t cap,
+                                           size_t *out_len, uint32_t *dict_id_needed) {
+  if (!c || !consumed || !out_len) return LZ4MI_RANGE;
+  *consumed = 0;
+  *out_len = 0;
+  LZ4MI_HIP(c, hipSetDevice(c->device));
+  if (len < 4) return LZ4MI_FORMAT_EOF;  // lz4_frame_decoder.dart:53-55
+  const uint32_t magic = rd32(src);
+  size_t off = 4;
+  if ((magic & 0xFFFFFFF0u) == kSkippableBase) {  // :59-62, :78-84
+    if (len - off < 4) return LZ4MI_FORMAT_EOF;
+    uint32_t size = rd32(src + off);
+    off += 4;
+    if (size > len - off) return LZ4MI_FORMAT_EOF;
+    *consumed = off + size;
+    return LZ4MI_OK;
+  }
+
+  if (magic == kLegacyMagic) {  // :86-136
+    const size_t legacy_max = 8u << 20;
+    std::vector<Blk> blocks;
+    int32_t walk_err = 0;
+    bool last_has_next = false;  // a non-boundary word follows the last collected block
+    auto boundary = [](uint32_t m) {
+      return m == kFrameMagic || m == kLegacyMagic || (m & 0xFFFFFFF0u) == kSkippableBase;
+    };
+    for (;;) {
+      if (len - off == 0) break;
+      if (len - off < 4) { walk_err = LZ4MI_FORMAT_EOF; break; }
+      uint32_t w = rd32(src + off);
+      if (boundary(w)) break;
+      off += 4;
+      if (w == 0) { walk_err = LZ4MI_CORRUPT_LEGACY_SIZE; last_has_next = true; break; }
+      if (w > len - off) { walk_err = LZ4MI_FORMAT_EOF; last_has_next = true; break; }
+      Blk k = {off, w, 0, 0, 0};
+      blocks.push_back(k);
+      off += w;
+      if (len - off != 0 && len - off < 4) {  // :124-126, raised after this block has been decoded
+        walk_err = LZ4MI_FORMAT_EOF;
+        break;
+      }
+    }
+    uint32_t unused = 0;
+    int32_t st = decode_blocks(c, src, off, blocks, legacy_max, true, nullptr, 0, false, walk_err, max_out, false,
+                               true, last_has_next, dst, cap, out_len, &unused);
+    if (st) return st;
+    *consumed = off;
+    return LZ4MI_OK;
+  }
+  if (magic != kFrameMagic) return LZ4MI_FORMAT_MAGIC;  // :70-72
+
+  Header h;
+  int32_t st = parse_header(src + off, len - off, &h);
+  if (st) return st;
+  bool have_dict = have_prev_dict != 0;  // _dict persists across frames (:34,235)
+  if (h.has_dict) {                      // :225-236
+    if (dict_state == 0) {
+      if (dict_id_needed) *dict_id_needed = h.dict_id;
+      return LZ4MI_NEED_DICT;
+    }
+    if (dict_state == 2) return LZ4MI_UNSUPPORTED_DICT;
+    if (dict_state == 3) {
+      if (dict_id_needed) *dict_id_needed = h.dict_id;
+      return LZ4MI_DICT_NOT_FOUND;
+    }
+    have_dict = true;
+  }
+  if (!have_dict) { dict = nullptr; dict_len = 0; }
+  off += h.len;
+
+  std::vector<Blk> blocks;
+  int32_t walk_err = 0;
+  bool ended = false;
+  for (;;) {  // :238-304, structure only
+    if (len - off < 4) { walk_err = LZ4MI_FORMAT_EOF; break; }
+    uint32_t raw = rd32(src + off);
+    off += 4;
+    if (raw == 0) { ended = true; break; }
+    uint32_t size = raw & 0x7FFFFFFFu;
+    if (size > h.bmax) { walk_err = LZ4MI_CORRUPT_BLOCK_SIZE; break; }
+    if (size > len - off) { walk_err = LZ4MI_FORMAT_EOF; break; }
+    Blk k = {off, size, (raw >> 31) & 1u, 0, 0};
+    off += size;
+    if (h.block_ck) {
+      if (len - off < 4) { walk_err = LZ4MI_FORMAT_EOF; break; }
+      k.has_ck = 1;
+      k.ck = rd32(src + off);
+      off += 4;
+    }
+    blocks.push_back(k);
+  }
+  uint32_t expected_content = 0;
+  int32_t tail_err = 0;
+  if (ended && h.content_ck) {  // :306-310
+    if (len - off < 4) tail_err = LZ4MI_FORMAT_EOF;
+    else { expected_content = rd32(src + off); off += 4; }
+  }
+  uint32_t content_hash = 0;
+  st = decode_blocks(c, src, off, blocks, h.bmax, h.indep != 0, dict, dict_len, have_dict, walk_err, max_out,
+                     ended && h.content_ck && !tail_err, false, false, dst, cap, out_len, &content_hash);
+  if (st) return st;
+  if (tail_err) return tail_err;
+  if (h.content_ck && content_hash != expected_content) return LZ4MI_CORRUPT_CONTENT_CK;  // :311-314
+  if (h.has_size && (uint64_t)*out_len != h.content_size) return LZ4MI_CORRUPT_CONTENT_SIZE;  // :317-321
+  *consumed = off;
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound_out) {
+  if (!bound_out) return LZ4MI_RANGE;
+  *bound_out = 0;
+  if (len < 4) return LZ4MI_OK;
+  const uint32_t magic = rd32(src);
+  size_t off = 4;
+  if ((magic & 0xFFFFFFF0u) == kSkippableBase) return LZ4MI_OK;
+  size_t bmax = 8u << 20;
+  bool ck = false;
+  if (magic == kFrameMagic) {
+    Header h;
+    if (parse_header(src + off, len - off, &h)) return LZ4MI_OK;
+    off += h.len;
+    bmax = h.bmax;
+    ck = h.block_ck != 0;
+  } else if (magic != kLegacyMagic) {
+    return LZ4MI_OK;
+  }
+  size_t nb = 0;
+  while (len - off >= 4) {
+    uint32_t raw = rd32(src + off);
+    if (magic == kLegacyMagic &&
+        (raw == kFrameMagic || raw == kLegacyMagic || (raw & 0xFFFFFFF0u) == kSkippableBase))
+      break;
+    off += 4;
+    if (raw == 0) break;
+    uint32_t size = raw & 0x7FFFFFFFu;
+    if (size > len - off) break;
+    off += size + (ck ? 4 : 0);
+    if (off > len) break;
+    nb++;
+  }
+  *bound_out = nb * bmax;
+  return LZ4MI_OK;
+}

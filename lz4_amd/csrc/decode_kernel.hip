@@ -1,0 +1,276 @@
+// LZ4 block decoder for gfx950: one wavefront per block.
+//
+// Follows lz4BlockDecompress (strict) and lz4BlockDecompressInto (lenient) of
+// lib/src/block/lz4_block_decoder.dart:7-119 with ByteWriter.copyMatch
+// (lib/src/internal/byte_writer.dart:93-121) check for check, so the status of
+// a malformed block equals the exception the reference raises.
+//
+// Layout: the token stream is parsed wave-uniformly out of a 512-byte register
+// window of the compressed block (two dwords per lane, fetched with one
+// coalesced load and read back with v_readlane), so the parse chain never
+// waits on memory.  Literal and match bytes are moved by all 64 lanes:
+// 16-byte aligned stores for long runs, a byte per lane for short ones, and a
+// modulo-period gather for matches that overlap their own output.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lz4mi {
+
+struct InWindow {
+  const uint8_t *al;   // 4-byte aligned base (src - mis)
+  uint32_t mis;        // src - al, 0..3
+  uint32_t vend;       // mis + src_len rounded up to 4
+  uint32_t base;       // window start in v-space (multiple of 4), covers [base, base+512)
+  uint32_t w0, w1;     // per-lane dwords
+  uint32_t nbase;      // prefetched next window
+  uint32_t n0, n1;
+};
+
+__device__ __forceinline__ void win_load(const InWindow &w, uint32_t base, uint32_t lane, uint32_t &r0,
+                                         uint32_t &r1) {
+  uint32_t p0 = base + 4 * lane, p1 = p0 + 256;
+  r0 = p0 < w.vend ? *(const uint32_t *)(w.al + p0) : 0u;
+  r1 = p1 < w.vend ? *(const uint32_t *)(w.al + p1) : 0u;
+}
+
+__device__ __forceinline__ void win_seek(InWindow &w, uint32_t vpos, uint32_t lane) {
+  if (vpos - w.nbase < 512u) {  // forward into the prefetched window
+    w.w0 = w.n0;
+    w.w1 = w.n1;
+    w.base = w.nbase;
+  } else {
+    w.base = vpos & ~3u;
+    win_load(w, w.base, lane, w.w0, w.w1);
+  }
+  w.nbase = w.base + 512;
+  win_load(w, w.nbase, lane, w.n0, w.n1);
+}
+
+// byte at real offset `pos` of the compressed block (caller guarantees pos < src_len)
+__device__ __forceinline__ uint32_t win_byte(InWindow &w, uint32_t pos, uint32_t lane) {
+  uint32_t v = pos + w.mis;
+  if (v - w.base >= 512u) win_seek(w, v, lane);
+  uint32_t rel = v - w.base;
+  uint32_t d = rel >> 2;
+  uint32_t a = rdlane(w.w0, d & 63u), b = rdlane(w.w1, d & 63u);
+  uint32_t word = (d & 64u) ? b : a;
+  return (word >> ((rel & 3u) * 8u)) & 0xffu;
+}
+
+// Sum of length-extension bytes (lz4_block_decoder.dart:121-130).  Returns false on
+// running off the end of the input ('Unexpected end of input', byte_reader.dart:102-106).
+__device__ __forceinline__ bool read_ext(InWindow &w, const uint8_t *__restrict__ src, uint32_t &ip,
+                                         uint32_t in_end, uint64_t &len, uint32_t lane) {
+  // a few bytes through the register window, then 64 bytes per step with a ballot
+  for (int k = 0; k < 3; k++) {
+    if (ip >= in_end) return false;
+    uint32_t b = win_byte(w, ip, lane);
+    ip++;
+    len += b;
+    if (b != 255u) return true;
+  }
+  for (;;) {
+    uint32_t p = ip + lane;
+    uint32_t b = p < in_end ? (uint32_t)src[p] : 0x100u;  // 0x100 marks "past the end"
+    uint64_t stop = ballot(b != 255u);
+    if (stop == 0) {
+      len += 255u * 64u;
+      ip += 64;
+      continue;
+    }
+    uint32_t f = (uint32_t)__builtin_ctzll(stop);
+    uint32_t bf = rdlane(b, f);
+    len += 255u * f;
+    if (bf == 0x100u) {
+      ip += f;
+      return false;
+    }
+    len += bf;
+    ip += f + 1;
+    return true;
+  }
+}
+
+template <bool HAS_PREFIX>
+__device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t dist, uint32_t ml,
+                                           const uint8_t *__restrict__ prefix, uint32_t prefix_len,
+                                           uint32_t lane) {
+  int64_t s = (int64_t)op - (int64_t)dist;  // source start relative to dst; < 0 reaches into the prefix
+  if (dist >= ml) {
+    if (!HAS_PREFIX || s >= 0) {
+      wave_copy(dst + op, dst + s, ml, lane);
+    } else {
+      uint32_t npre = (uint32_t)(-s) < ml ? (uint32_t)(-s) : ml;
+      wave_copy(dst + op, prefix + prefix_len + s, npre, lane);
+      if (ml > npre) wave_copy(dst + op + npre, dst, ml - npre, lane);
+    }
+    return;
+  }
+  // Overlapping match: byte-serial forward copy semantics (byte_writer.dart:116-118)
+  // == replication of the period [op-dist, op), which is complete before the match starts.
+  uint32_t r = dist >= kWave ? lane : lane % dist;
+  uint32_t step = dist > kWave ? kWave : kWave % dist;
+  for (uint32_t k = lane; k < ml; k += kWave) {
+    int64_t sp = s + r;
+    uint8_t v;
+    if (HAS_PREFIX && sp < 0)
+      v = prefix[(int64_t)prefix_len + sp];
+    else
+      v = dst[sp];
+    dst[op + k] = v;
+    r += step;
+    if (r >= dist) r -= dist;
+  }
+}
+
+// Decodes one block with the whole wave into dst[op_start ...).  `cap` is
+// decompressedSize (STRICT) or the ByteWriter maxLength minus the pre-filled prefix
+// (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
+// non-negative positions come from dst itself (earlier blocks of a linked frame),
+// negative positions from the tail of `prefix` (dictionary).  out_len = bytes written.
+template <bool STRICT, bool HAS_PREFIX>
+__device__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
+                                const uint64_t op_start, uint32_t cap, uint32_t back_limit,
+                                const uint8_t *__restrict__ prefix, uint32_t prefix_len, uint32_t lane,
+                                uint32_t &out_len) {
+  InWindow w;
+  w.mis = (uint32_t)((uintptr_t)src & 3u);
+  w.al = src - w.mis;
+  w.vend = (w.mis + src_len + 3u) & ~3u;
+  w.base = 0xfffffc00u;  // nothing loaded yet
+  w.nbase = 0xfffff000u;
+  w.w0 = w.w1 = w.n0 = w.n1 = 0;
+
+  uint32_t ip = 0, op = 0;  // op counts bytes written by this block
+  const uint32_t in_end = src_len;
+  int32_t st = LZ4MI_OK;
+
+  for (;;) {
+    if (STRICT) {
+      if (op >= cap) {  // loop condition :21, then the trailing check :72-74
+        if (ip != in_end) st = LZ4MI_CORRUPT_TRAILING;
+        break;
+      }
+      if (ip >= in_end) { st = LZ4MI_FORMAT_EOF; break; }  // :22-24
+    } else {
+      if (ip >= in_end) break;  // :86-88
+    }
+    uint32_t token = win_byte(w, ip, lane);
+    ip++;
+    uint64_t lit = token >> 4;
+    if (lit == 15) {
+      if (!read_ext(w, src, ip, in_end, lit, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+    }
+    if (STRICT && lit > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_LITERAL; break; }  // :33-35
+    if (lit != 0) {
+      if (lit > (uint64_t)(in_end - ip)) { st = LZ4MI_FORMAT_EOF; break; }  // readBytesView
+      if (!STRICT && lit > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; } // writer maxLength
+      wave_copy(dst + op_start + op, src + ip, (uint32_t)lit, lane);
+      ip += (uint32_t)lit;
+      op += (uint32_t)lit;
+    }
+    if (STRICT) {
+      if (op == cap) {  // :42-48
+        if (ip != in_end) st = LZ4MI_CORRUPT_TRAILING;
+        break;
+      }
+    } else {
+      if (ip >= in_end) break;  // :102-104
+    }
+    if (in_end - ip < 2) { st = LZ4MI_FORMAT_EOF; break; }  // :50-52 / :106-108
+    uint32_t dist = win_byte(w, ip, lane);
+    dist |= win_byte(w, ip + 1, lane) << 8;
+    ip += 2;
+    uint64_t ml = (token & 15u) + 4u;
+    if ((token & 15u) == 15u) {
+      if (!read_ext(w, src, ip, in_end, ml, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+    }
+    if (STRICT && ml > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_MATCH; break; }  // :61-63
+    // copyMatch: distance first (byte_writer.dart:97-99), then capacity (:104)
+    if (dist == 0 || (uint64_t)dist > (uint64_t)op + back_limit) { st = LZ4MI_CORRUPT_DISTANCE; break; }
+    if (!STRICT && ml > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; }
+    copy_match<HAS_PREFIX>(dst, op_start + op, dist, (uint32_t)ml, prefix, prefix_len, lane);
+    op += (uint32_t)ml;
+  }
+  out_len = op;
+  return st;
+}
+
+template <bool STRICT, bool HAS_PREFIX>
+__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter) {
+  const uint32_t lane = lane_id();
+  // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
+  const uint8_t *prefix = a.dict;
+  uint32_t prefix_len = a.dict_len;
+  for (;;) {
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(counter, 1u);
+    b = uni(b);
+    if (b >= a.nblocks) break;
+    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    uint32_t src_len = uni(block_src_len(a, b));
+    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
+    uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t out_len = 0;
+    int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, lane,
+                                                  out_len);
+    if (lane == 0) {
+      a.out_len[b] = out_len;
+      a.status[b] = st;
+    }
+  }
+}
+
+// Linked ("dependent") blocks: block b may reference the 64 KiB that precede it in the
+// frame output, topped up from the dictionary while the output is shorter than that
+// (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
+// serial, so one wavefront walks the blocks in order over one contiguous output.
+__global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
+  const uint32_t lane = lane_id();
+  uint64_t start = 0;
+  uint32_t b = 0;
+  for (; b < c.nblocks; b++) {
+    const uint8_t *payload = c.src + c.payload_off[b];
+    const uint32_t len = c.payload_len[b];
+    uint32_t produced = 0;
+    int32_t st = LZ4MI_OK;
+    if (c.raw[b]) {
+      wave_copy(c.dst + start, payload, len, lane);
+      produced = len;
+    } else {
+      uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
+      if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
+      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, lane,
+                                     produced);
+    }
+    if (lane == 0) {
+      c.out_len[b] = produced;
+      c.status[b] = st;
+    }
+    if (st != LZ4MI_OK) { b++; break; }
+    start += produced;
+  }
+  for (uint32_t k = b + lane; k < c.nblocks; k += kWave) {  // blocks after an error never ran
+    c.out_len[k] = 0;
+    c.status[k] = LZ4MI_OK;
+  }
+}
+
+void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
+  if (!c.nblocks) return;
+  hipLaunchKernelGGL(decode_chain_kernel, dim3(1), dim3(64), 0, s, c);
+}
+
+void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t grid, hipStream_t s) {
+  dim3 g(grid), blk(256);
+  bool pre = a.dict_len != 0;
+  if (strict) {
+    if (pre) hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter);
+    else hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter);
+  } else {
+    if (pre) hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter);
+    else hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter);
+  }
+}
+
+}  // namespace lz4mi

@@ -1,0 +1,276 @@
+// Fast LZ4 block encoder for gfx950: one wavefront per block, byte-identical to
+// lz4BlockCompressToWriter (lib/src/block/lz4_block_encoder.dart:35-157).
+//
+// The reference parse is a serial greedy scan, but between two matches its
+// probe positions are a fixed schedule  i_{k+1} = i_k + 1 + ((i_k - anchor) >> accel)
+// (:150).  A wavefront therefore evaluates a whole run of probes at once:
+// lane k gathers the 4 bytes at i_k, hashes them ((seq * 2654435761) >> 16, :167-170),
+// gathers the table entry, gathers the candidate's 4 bytes and votes; the first
+// hitting lane is the reference's next match.  Two facts keep this exact:
+//   * the table only ever holds the LARGEST position inserted per bucket (every
+//     insert of :100 and :139-145 is at a position larger than what the bucket
+//     held), so inserts are unordered atomic-max operations;
+//   * probes of the same run that share a bucket see each other in lane order
+//     (resolved in registers before the vote).
+// Inside a match of distance d only the last d positions can survive in the
+// table (position j and j+d hash the same bytes and j+d is inserted later), so
+// the interior re-hash (:139-145) touches min(length-4, d) positions.
+//
+// Table: 65536 x u32 per wavefront slot in HBM/L2, entry = generation<<23 | (pos+1);
+// a stale generation reads as empty, so a slot is reused without clearing.
+// A shared dictionary is primed once into a read-only table consulted when the
+// slot entry is empty (dictionary positions are always smaller than block positions).
+#include "device_common.h"
+#include "kernels.h"
+
+namespace lz4mi {
+
+struct EncIn {
+  const uint8_t *dict;  // last <=65535 dictionary bytes (positions [0, D))
+  const uint8_t *src;   // block bytes (positions [D, total))
+  uint32_t D;
+  uint32_t total;
+};
+
+template <bool HAS_DICT>
+__device__ __forceinline__ uint32_t in_byte(const EncIn &in, uint32_t pos) {
+  if (HAS_DICT && pos < in.D) return in.dict[pos];
+  return in.src[pos - in.D];
+}
+
+template <bool HAS_DICT>
+__device__ __forceinline__ uint32_t in_ld32(const EncIn &in, uint32_t pos) {
+  if (!HAS_DICT) return ld32(in.src + pos);
+  if (pos >= in.D) return ld32(in.src + (pos - in.D));
+  if (pos + 4 <= in.D) return ld32(in.dict + pos);
+  uint32_t v = 0;
+  for (uint32_t k = 0; k < 4; k++) v |= in_byte<true>(in, pos + k) << (8 * k);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t hash16(uint32_t seq) { return (seq * 2654435761u) >> 16; }
+
+__device__ __forceinline__ uint32_t sched_next(uint32_t o, uint32_t sh) {
+  return o < 0x40000000u ? o + 1u + (o >> sh) : o;
+}
+
+__device__ __forceinline__ uint32_t tbl_load(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void tbl_max(uint32_t *p, uint32_t v) {
+  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// 255-run length extension (:216-223): q bytes of 255 then the remainder.
+__device__ __forceinline__ uint32_t emit_len(uint8_t *out, uint32_t op, uint32_t v, uint32_t lane) {
+  uint32_t q = v / 255u, r = v - q * 255u;
+  for (uint32_t k = lane; k <= q; k += kWave) out[op + k] = k < q ? (uint8_t)255 : (uint8_t)r;
+  return op + q + 1;
+}
+
+template <bool HAS_DICT>
+__device__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
+                                     uint32_t *T, const uint32_t *__restrict__ dictT, uint32_t gen,
+                                     uint32_t offA, uint32_t offB, uint32_t lane, uint32_t &out_len) {
+  const uint32_t D = HAS_DICT ? in.D : 0u;
+  const uint32_t total = in.total;
+  const uint32_t n = total - D;
+  out_len = 0;
+  if (n == 0) return LZ4MI_OK;  // :45-48
+  if ((uint64_t)cap < (uint64_t)n + n / 255u + 16u) return LZ4MI_DST_TOO_SMALL;
+  const uint32_t gtag = gen << kPosBits;
+  uint32_t anchor = D, op = 0;
+
+  if (n >= 4) {  // :74-78
+    while (anchor + 4 <= total) {
+      bool matched = false;
+      uint32_t o_last = 0;
+      for (uint32_t chunk = 0;; chunk++) {
+        uint32_t o, nl;
+        if (chunk == 0) {
+          o = offA; nl = 8;
+        } else if (chunk == 1) {
+          o = offB; nl = kWave;
+        } else {
+          o = o_last; nl = kWave;
+          for (uint32_t t = 0; t < kWave; t++)
+            if (t <= lane) o = sched_next(o, sh);
+        }
+        uint32_t ik = anchor + o;
+        bool valid = lane < nl && ik + 4 <= total;
+        uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));  // valid lanes form a prefix
+        if (nvalid == 0) break;
+        uint32_t seq = 0, h = 0;
+        int32_t ref = -1;
+        if (valid) {
+          seq = in_ld32<HAS_DICT>(in, ik);
+          h = hash16(seq);
+          uint32_t e = tbl_load(T + h);
+          if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
+          else if (HAS_DICT) ref = (int32_t)dictT[h] - 1;
+        }
+        // earlier probes of this chunk that land in the same bucket (:99-100 in program order)
+        for (uint32_t j = 0; j + 1 < nvalid; j++) {
+          uint32_t hj = rdlane(h, j);
+          if (ballot(valid && lane > j && h == hj)) {
+            uint32_t ij = rdlane(ik, j);
+            if (valid && lane > j && h == hj) ref = (int32_t)ij;
+          }
+        }
+        bool hit = false;
+        if (valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu)  // :102-103
+          hit = in_ld32<HAS_DICT>(in, (uint32_t)ref) == seq;
+        uint64_t hm = ballot(hit);
+        uint32_t K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
+        if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe up to the hit
+        if (hm) {
+          const uint32_t i = rdlane(ik, K);
+          const uint32_t r0 = rdlane((uint32_t)ref, K);
+          const uint32_t dist = i - r0;
+          // backward extension :107-113
+          uint32_t maxb = i - anchor < r0 ? i - anchor : r0;
+          uint32_t b = 0;
+          while (b < maxb) {
+            uint32_t t = b + lane;
+            bool same = t < maxb && in_byte<HAS_DICT>(in, i - 1 - t) == in_byte<HAS_DICT>(in, r0 - 1 - t);
+            uint64_t m = ballot(!same);
+            if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
+            b += kWave;
+          }
+          const uint32_t ms = i - b;
+          // forward extension :117-121 (no end-of-block margin)
+          uint32_t fwd = 0;
+          for (;;) {
+            uint32_t pp = i + 4 + fwd + 4 * lane;
+            uint32_t avail = pp < total ? (total - pp < 4 ? total - pp : 4u) : 0u;
+            uint32_t eq = 0;
+            if (avail == 4) {
+              uint32_t x = in_ld32<HAS_DICT>(in, pp) ^ in_ld32<HAS_DICT>(in, pp - dist);
+              eq = x ? ((uint32_t)__builtin_ctz(x) >> 3) : 4u;
+            } else {
+              for (uint32_t k = 0; k < avail; k++) {
+                if (in_byte<HAS_DICT>(in, pp + k) != in_byte<HAS_DICT>(in, pp - dist + k)) break;
+                eq++;
+              }
+            }
+            uint64_t m = ballot(eq < 4);
+            if (m) {
+              uint32_t L = (uint32_t)__builtin_ctzll(m);
+              fwd += 4 * L + rdlane(eq, L);
+              break;
+            }
+            fwd += 4 * kWave;
+          }
+          const uint32_t ml = b + 4 + fwd;
+          const uint32_t lit = ms - anchor;
+          // _writeSequence :172-200
+          const uint32_t m4 = ml - 4;
+          if (lane == 0) out[op] = (uint8_t)(((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u));
+          op++;
+          if (lit >= 15) op = emit_len(out, op, lit - 15, lane);
+          if (lit) wave_copy(out + op, in.src + (anchor - D), lit, lane);
+          op += lit;
+          if (lane == 0) {
+            out[op] = (uint8_t)dist;
+            out[op + 1] = (uint8_t)(dist >> 8);
+          }
+          op += 2;
+          if (m4 >= 15) op = emit_len(out, op, m4 - 15, lane);
+          anchor = ms + ml;  // :132-133
+          matched = true;
+          if (anchor + 4 <= total) {  // :135-145 interior re-hash, last `dist` positions only
+            uint32_t hi = anchor - 4;
+            uint32_t lo = ms + 1;
+            if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
+            for (uint32_t j = lo + lane; j <= hi; j += kWave)
+              tbl_max(T + hash16(in_ld32<HAS_DICT>(in, j)), gtag | (j + 1));
+          }
+          break;
+        }
+        if (nvalid < nl) break;  // schedule ran past total-4 without a hit
+        o_last = rdlane(o, nl - 1);
+      }
+      if (!matched) break;
+    }
+  }
+  // _writeLastLiterals :153-156, :202-214
+  const uint32_t last = total - anchor;
+  if (last != 0) {
+    if (lane == 0) out[op] = (uint8_t)((last < 15 ? last : 15u) << 4);
+    op++;
+    if (last >= 15) op = emit_len(out, op, last - 15, lane);
+    wave_copy(out + op, in.src + (anchor - D), last, lane);
+    op += last;
+  }
+  out_len = op;
+  return LZ4MI_OK;
+}
+
+template <bool HAS_DICT>
+__global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t sh, EncodeScratch sc,
+                                                          uint32_t *counter) {
+  const uint32_t lane = lane_id();
+  const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  uint32_t *T = sc.tables + (size_t)slot * kHashEntries;
+  uint32_t gen = uni(sc.slot_gen[slot]);
+
+  // probe schedule: offA = off(lane), offB = off(lane + 8)
+  uint32_t offA = 0, offB = 0;
+  {
+    uint32_t o = 0;
+    for (uint32_t t = 0; t < kWave + 8; t++) {
+      if (t == lane) offA = o;
+      if (t == lane + 8) offB = o;
+      o = sched_next(o, sh);
+    }
+  }
+
+  EncIn in;
+  in.dict = a.dict;
+  in.D = a.dict_len;
+  for (;;) {
+    uint32_t b = 0;
+    if (lane == 0) b = atomicAdd(counter, 1u);
+    b = uni(b);
+    if (b >= a.nblocks) break;
+    if (++gen > kGenMax) {  // generation wrapped: clear the slot
+      for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(T + k) = make_uint4(0, 0, 0, 0);
+      gen = 1;
+    }
+    in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    in.total = in.D + uni(block_src_len(a, b));
+    uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
+    uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t out_len = 0;
+    int32_t st = encode_block_fast<HAS_DICT>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, lane, out_len);
+    if (lane == 0) {
+      a.out_len[b] = out_len;
+      a.status[b] = st;
+    }
+  }
+  if (lane == 0) sc.slot_gen[slot] = gen;
+}
+
+// Dictionary priming (:83-88): bucket <- largest dictionary position + 1.
+__global__ void dict_prime_kernel(const uint8_t *__restrict__ dict, uint32_t dict_len, uint32_t *table) {
+  uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pos + 4 <= dict_len) atomicMax(table + hash16(ld32(dict + pos)), pos + 1);
+}
+
+void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_table, hipStream_t s) {
+  (void)hipMemsetAsync(dict_table, 0, kHashEntries * sizeof(uint32_t), s);
+  if (dict_len >= 4) {
+    uint32_t n = dict_len - 3;
+    hipLaunchKernelGGL(dict_prime_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dict, dict_len, dict_table);
+  }
+}
+
+void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
+                        uint32_t grid, hipStream_t s) {
+  if (a.dict_len)
+    hipLaunchKernelGGL((encode_fast_kernel<true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else
+    hipLaunchKernelGGL((encode_fast_kernel<false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+}
+
+}  // namespace lz4mi

@@ -1,0 +1,121 @@
+// Frame assembly kernels: the bookkeeping half of the frame block dispatcher
+// (lib/src/frame/lz4_frame_encoder.dart:209-258): stored-vs-compressed choice,
+// record offsets by exclusive prefix sum, size/checksum words, payload gather.
+#include "device_common.h"
+#include "kernels.h"
+#include "frame_kernels.h"
+
+namespace lz4mi {
+
+// Per block: stored length, raw flag, record size, payload source address.
+// Stored compressed iff c < n, strictly (lz4_frame_encoder.dart:235).
+__global__ void frame_plan_kernel(FramePlanArgs p) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.nblocks) return;
+  uint64_t start = (uint64_t)b * p.block_max;
+  uint32_t n = (uint32_t)(p.src_total - start < p.block_max ? p.src_total - start : p.block_max);
+  uint32_t c = p.comp_len[b];
+  bool raw = !(c < n);
+  uint32_t stored = raw ? n : c;
+  p.stored_word[b] = raw ? (0x80000000u | n) : c;
+  p.payload_addr[b] = raw ? (uint64_t)(uintptr_t)(p.src + start)
+                          : (uint64_t)(uintptr_t)(p.comp + (uint64_t)b * p.comp_stride);
+  p.payload_len[b] = stored;
+  p.record_size[b] = 4u + stored + (p.block_checksum ? 4u : 0u);
+}
+
+// Exclusive prefix sum of u32 sizes into u64 offsets (+ base); single workgroup.
+// total[0] receives base + sum.
+__global__ __launch_bounds__(1024) void scan_sizes_kernel(const uint32_t *sizes, uint32_t n, uint64_t base,
+                                                          uint64_t *offsets, uint64_t *total) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t lo = t * per < n ? t * per : n;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  uint64_t s = 0;
+  for (uint32_t k = lo; k < hi; k++) s += sizes[k];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+    uint64_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint64_t run = base + (t ? part[t - 1] : 0);
+  for (uint32_t k = lo; k < hi; k++) {
+    offsets[k] = run;
+    run += sizes[k];
+  }
+  if (t == 1023) total[0] = base + part[1023];
+}
+
+__device__ __forceinline__ void put_u32le(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
+
+// Size word in front of each record and the optional xxh32 word behind the payload.
+__global__ void frame_words_kernel(uint8_t *frame, const uint64_t *rec_off, const uint32_t *stored_word,
+                                   const uint32_t *payload_len, const uint32_t *hashes, uint32_t nblocks) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  uint8_t *r = frame + rec_off[b];
+  put_u32le(r, stored_word[b]);
+  if (hashes) put_u32le(r + 4 + payload_len[b], hashes[b]);
+}
+
+// One workgroup per segment: dst_base + dst_off[k] + dst_delta  <-  (uint8_t*)src_addr[k], len[k] bytes.
+__global__ __launch_bounds__(256) void seg_copy_kernel(const uint64_t *src_addr, uint8_t *dst_base,
+                                                       const uint64_t *dst_off, uint64_t dst_delta,
+                                                       const uint32_t *len, uint32_t nseg) {
+  for (uint32_t k = blockIdx.x; k < nseg; k += gridDim.x) {
+    const uint8_t *src = (const uint8_t *)(uintptr_t)src_addr[k];
+    uint8_t *dst = dst_base + dst_off[k] + dst_delta;
+    uint32_t n = len[k];
+    const uint32_t t = threadIdx.x;
+    uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;
+    if (head > n) head = n;
+    if (t < head) dst[t] = src[t];
+    dst += head;
+    src += head;
+    n -= head;
+    uint32_t body = n & ~15u;
+    for (uint32_t off = t * 16; off < body; off += 256 * 16) st128(dst + off, ld128(src + off));
+    uint32_t tail = n - body;
+    if (t < tail) dst[body + t] = src[body + t];
+  }
+}
+
+__global__ void put_words_kernel(uint8_t *dst, const uint32_t *words, uint32_t nwords, uint32_t literal0,
+                                 int use_literal0) {
+  // trailer: end mark (literal 0) followed by device-computed words
+  uint32_t t = threadIdx.x;
+  if (use_literal0 && t == 0) put_u32le(dst, literal0);
+  if (t < nwords) put_u32le(dst + (use_literal0 ? 4 : 0) + 4 * t, words[t]);
+}
+
+void launch_frame_plan(const FramePlanArgs &p, hipStream_t s) {
+  if (!p.nblocks) return;
+  hipLaunchKernelGGL(frame_plan_kernel, dim3((p.nblocks + 255) / 256), dim3(256), 0, s, p);
+}
+void launch_scan_sizes(const uint32_t *sizes, uint32_t n, uint64_t base, uint64_t *offsets, uint64_t *total,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, s, sizes, n, base, offsets, total);
+}
+void launch_frame_words(uint8_t *frame, const uint64_t *rec_off, const uint32_t *stored_word,
+                        const uint32_t *payload_len, const uint32_t *hashes, uint32_t nblocks, hipStream_t s) {
+  if (!nblocks) return;
+  hipLaunchKernelGGL(frame_words_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, frame, rec_off,
+                     stored_word, payload_len, hashes, nblocks);
+}
+void launch_seg_copy(const uint64_t *src_addr, uint8_t *dst_base, const uint64_t *dst_off, uint64_t dst_delta,
+                     const uint32_t *len, uint32_t nseg, hipStream_t s) {
+  if (!nseg) return;
+  uint32_t grid = nseg < 65536u ? nseg : 65536u;
+  hipLaunchKernelGGL(seg_copy_kernel, dim3(grid), dim3(256), 0, s, src_addr, dst_base, dst_off, dst_delta, len,
+                     nseg);
+}
+void launch_put_words(uint8_t *dst, const uint32_t *words, uint32_t nwords, bool end_mark, hipStream_t s) {
+  hipLaunchKernelGGL(put_words_kernel, dim3(1), dim3(64), 0, s, dst, words, nwords, 0u, end_mark ? 1 : 0);
+}
+
+}  // namespace lz4mi

@@ -1,0 +1,71 @@
+// Host-visible launch interface of the gfx950 kernels (internal to liblz4mi).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lz4mi {
+
+// Resolved form of lz4mi_batch: every pointer is device memory.
+struct BatchArgs {
+  const uint8_t *src;
+  const uint64_t *src_off;
+  const uint32_t *src_len;
+  uint64_t src_stride;
+  uint32_t src_len_uniform;
+  uint64_t src_total;
+  uint8_t *dst;
+  const uint64_t *dst_off;
+  uint64_t dst_stride;
+  const uint32_t *dst_cap;
+  uint32_t dst_cap_uniform;
+  const uint8_t *dict;
+  uint32_t dict_len;
+  uint32_t nblocks;
+  uint32_t *out_len;
+  int32_t *status;
+};
+
+__host__ __device__ inline uint32_t block_src_len(const BatchArgs &a, uint32_t b) {
+  if (a.src_len) return a.src_len[b];
+  uint64_t start = (uint64_t)b * a.src_len_uniform;
+  uint64_t left = a.src_total > start ? a.src_total - start : 0;
+  return left < a.src_len_uniform ? (uint32_t)left : a.src_len_uniform;
+}
+
+// Position field / generation tag split of a hash-table entry (encoder).
+constexpr uint32_t kPosBits = 24;               // positions < 16 MiB (block + 64 KiB dictionary)
+constexpr uint32_t kPosMask = (1u << kPosBits) - 1;
+constexpr uint32_t kGenMax = (1u << (32 - kPosBits)) - 1;
+constexpr uint32_t kHashEntries = 65536;
+
+struct EncodeScratch {
+  uint32_t *tables;    // nslots * 65536 entries
+  uint32_t *slot_gen;  // nslots generation counters
+  uint32_t *dict_table;// 65536 entries primed from the shared dictionary (or null)
+  uint32_t nslots;
+};
+
+struct ChainArgs {
+  const uint8_t *src;           // frame bytes (device)
+  const uint64_t *payload_off;  // per block: payload offset in src
+  const uint32_t *payload_len;
+  const uint32_t *raw;          // per block: nonzero = stored uncompressed
+  uint32_t nblocks;
+  uint32_t block_max;
+  uint8_t *dst;                 // contiguous frame output
+  const uint8_t *dict;
+  uint32_t dict_len;
+  uint32_t *out_len;
+  int32_t *status;
+};
+
+void launch_decode_chain(const ChainArgs &c, hipStream_t s);
+void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t grid, hipStream_t s);
+void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
+                        uint32_t grid, hipStream_t s);
+void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_table, hipStream_t s);
+void launch_xxh32_batch(const BatchArgs &a, uint32_t *d_hash, hipStream_t s);
+void launch_xxh32_serial(const uint8_t *d_data, uint64_t len, uint32_t seed, uint32_t *d_out, hipStream_t s);
+
+}  // namespace lz4mi

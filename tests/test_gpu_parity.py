@@ -1,0 +1,480 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the
+reference's golden vectors.  Bit-exact for bytes, exact for exception type+message.
+
+Run with `pytest -m gpu` on an MI355X.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLDEN_DIR, build_frame, corpus, corpus_block, golden, golden_frame, ramp, u32le
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lz():
+    import lz4_amd
+    return lz4_amd
+
+
+@pytest.fixture(scope="module")
+def codec():
+    import torch
+    from lz4_amd.device import DeviceCodec
+    assert torch.cuda.is_available()
+    return DeviceCodec(0)
+
+
+def _same_error(lz, oracle, gpu_call, ref_call):
+    """Both raise, with the same Dart class name and message."""
+    with pytest.raises(oracle.Lz4RefError) as ref:
+        ref_call()
+    with pytest.raises(Exception) as got:
+        gpu_call()
+    assert type(got.value).__name__ == ref.value.type_name, (got.value, ref.value)
+    assert getattr(got.value, "message", None) == ref.value.message or ref.value.type_name == "RangeError"
+
+
+# ------------------------------------------------------------------ xxh32
+
+def test_xxh32_reference_vectors(lz):
+    g = golden()["xxh32"]
+    gen = g["gen_seed"]
+    data = bytearray()
+    for _ in range(g["data_len"]):
+        data.append((gen >> 24) & 0xFF)
+        gen = (gen * gen) & 0xFFFFFFFF
+    for length, seed, expected in g["cases"]:
+        assert lz.xxh32(bytes(data[:length]), seed) == expected
+
+
+def test_xxh32_lengths_vs_oracle(lz, oracle):
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 40)) + [63, 64, 65, 255, 256, 257, 1000, 4097, 65536, 300001]:
+        d = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        for seed in (0, 0x9E3779B1):
+            assert lz.xxh32(d, seed) == oracle.xxh32(d, seed), n
+
+
+def test_xxh32_batch_vs_oracle(codec, oracle):
+    import torch
+    rng = np.random.default_rng(4)
+    lens = [0, 1, 3, 15, 16, 17, 31, 32, 33, 100, 255, 4096, 65536, 65537, 7, 64] * 3
+    offs, blob, pos = [], bytearray(), 0
+    for n in lens:
+        pos += int(rng.integers(0, 7))  # arbitrary alignment
+        blob += bytes(pos - len(blob))
+        offs.append(pos)
+        blob += rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        pos += n
+    t = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+    h = codec.xxh32_blocks(t, torch.tensor(lens, dtype=torch.int32, device="cuda"),
+                           offsets=torch.tensor(offs, dtype=torch.int64, device="cuda"))
+    got = h.cpu().numpy().view(np.uint32)
+    for k, n in enumerate(lens):
+        assert int(got[k]) == oracle.xxh32(bytes(blob[offs[k]:offs[k] + n])), (k, n)
+
+
+# ---------------------------------------------------------- block decoder
+
+def test_block_decoder_known_answers(lz):
+    for v in golden()["block_decoder_ok"]:
+        assert lz.lz4Decompress(bytes(v["src"]), decompressedSize=v["size"]) == bytes(v["out"]), v["name"]
+
+
+def test_block_decoder_malformed_matches_reference_types(lz):
+    for v in golden()["block_decoder_err"]:
+        with pytest.raises(Exception) as e:
+            lz.lz4Decompress(bytes(v["src"]), decompressedSize=v["size"])
+        assert type(e.value).__name__ == v["type"], v["name"]
+
+
+STRICT_CASES = [
+    (b"", 4), (bytes([0x50, 1, 2]), 5), (bytes([0x50, 1, 2, 3, 4, 5]), 4), (bytes([0x40, 1, 2, 3, 4, 4, 0]), 5),
+    (bytes([0x10, 1, 2]), 1), (bytes([0x10, 1, 5, 0]), 8), (bytes([0x00]), 0), (bytes([0xF0]), 20),
+    (bytes([0xF0, 255]), 400), (bytes([0x1F, 0x41, 1, 0]), 30), (bytes([0x1F, 0x41, 1, 0, 255]), 600),
+    (bytes([0x10, 0x41, 1]), 8), (bytes([0x40, 1, 2, 3, 4, 5, 0]), 12), (bytes([0x00, 0, 0]), 4),
+]
+
+
+def test_block_decoder_strict_error_parity(lz, oracle):
+    for src, size in STRICT_CASES:
+        _same_error(lz, oracle, lambda: lz.lz4Decompress(src, decompressedSize=size),
+                    lambda: oracle.block_decompress(src, size))
+    assert lz.lz4Decompress(b"", decompressedSize=0) == b""
+    with pytest.raises(Exception) as e:
+        lz.lz4Decompress(b"", decompressedSize=-1)
+    assert type(e.value).__name__ == "RangeError"
+
+
+LENIENT_CASES = [
+    (bytes([0x50, 1, 2]), b"", 1), (bytes([0x50, 1, 2, 3, 4, 5]), b"", 4), (bytes([0x1F, 0x41, 9, 0, 200]), b"", 4),
+    (bytes([0x1F, 0x41, 1, 0, 200]), b"", 4), (bytes([0x00, 4]), b"abcd", None), (bytes([0x00, 5, 0]), b"abcd", None),
+    (bytes([0xF0, 255, 255]), b"", None), (bytes([0x0F, 1, 0, 255, 255, 255]), b"x", None),
+]
+
+
+def test_block_decoder_lenient_parity(lz, oracle):
+    for src, prefix, maxlen in LENIENT_CASES:
+        _same_error(lz, oracle, lambda: lz.lz4BlockDecompressInto(src, prefix, maxlen),
+                    lambda: oracle.block_decompress_into(src, prefix, maxlen))
+    ok = [(b"", b""), (bytes([0x00]), b""), (bytes([0x10, 0x41]), b""), (bytes([0x00, 4, 0]), b"abcd"),
+          (bytes([0x00, 1, 0]), b"abcd"), (bytes([0x2F, 1, 2, 3, 0, 30]), b"abcd")]
+    for src, prefix in ok:
+        assert lz.lz4BlockDecompressInto(src, prefix) == oracle.block_decompress_into(src, prefix)
+
+
+def _mutations(rng, blocks, per_block):
+    out = []
+    for src, size in blocks:
+        out.append((src, size))
+        for _ in range(per_block):
+            b = bytearray(src)
+            kind = rng.integers(0, 4)
+            if kind == 0 and len(b):
+                b[int(rng.integers(0, len(b)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1 and len(b) > 1:
+                b = b[: int(rng.integers(0, len(b)))]
+            elif kind == 2:
+                b += bytes(rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8))
+            elif len(b):
+                p = int(rng.integers(0, len(b)))
+                b[p:p + 2] = bytes(rng.integers(0, 256, size=2, dtype=np.uint8))
+            out.append((bytes(b), size + int(rng.integers(-2, 3)) if rng.integers(0, 4) == 0 else size))
+    return out
+
+
+def test_block_decoder_fuzz_status_parity(codec, oracle):
+    """Bit flips / truncations / garbage (the reference's fuzz idea,
+    test/block/lz4_block_decoder_fuzz_test.dart:101-195): every block's status and,
+    when it decodes, every byte equals the oracle's, strict and lenient."""
+    import torch
+    from lz4_amd import _native as N
+    rng = np.random.default_rng(99)
+    base = []
+    for i in range(16):
+        n = int(rng.integers(1, 3000))
+        data = corpus_block(i, 4096).tobytes()[:n]
+        base.append((oracle.block_compress_hc(data, max_search_depth=8), n))
+        base.append((oracle.block_compress_fast(data), n))
+    cases = _mutations(rng, base, 20)
+    cases = [(s, max(0, z)) for s, z in cases]
+    offs, blob = [], bytearray()
+    for s, _ in cases:
+        offs.append(len(blob))
+        blob += s
+    blob += bytes(64)
+    comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+    sizes = torch.tensor([len(s) for s, _ in cases], dtype=torch.int32, device="cuda")
+    offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    expected = torch.tensor([z for _, z in cases], dtype=torch.int32, device="cuda")
+    slot = 4096
+    for strict in (True, False):
+        out, out_len, status = codec.decompress_blocks(comp, sizes, slot, comp_offsets=offsets,
+                                                       expected=expected, strict=strict)
+        out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+        for k, (s, z) in enumerate(cases):
+            try:
+                ref = oracle.block_decompress(s, z) if strict else oracle.block_decompress_into(s, b"", z)
+                ref_status = 0
+            except oracle.Lz4RefError as e:
+                ref, ref_status = None, e.status
+            assert int(status[k]) == ref_status, (strict, k, s[:16].hex(), z)
+            if ref is not None:
+                assert int(out_len[k]) == len(ref)
+                assert out[k, : len(ref)].tobytes() == ref
+    assert N.OK == 0
+
+
+# --------------------------------------------------------------- encoder
+
+def test_encoder_byte_known_answers(lz):
+    assert lz.lz4Compress(b"") == b""
+    assert lz.lz4Compress(bytes([1, 2, 3])) == bytes([0x30, 1, 2, 3])
+    assert lz.lz4Compress(b"abcdabcd") == bytes([0x40, 0x61, 0x62, 0x63, 0x64, 0x04, 0x00])
+    assert lz.lz4Compress(b"A" * 256) == bytes([0x1F, 0x41, 0x01, 0x00, 0xEC])
+    blk = lz.lz4Compress(ramp(65536))
+    assert blk == bytes([0xFF, 0x71]) + ramp(128) + bytes([0x80, 0x00]) + b"\xff" * 256 + bytes([0x6D])
+    assert len(lz.lz4Compress(ramp(1 << 20))) == golden()["encoder_sizes_repeating_1MiB"]["block_fast"]
+    for bad in (b"abc", b""):
+        with pytest.raises(Exception) as e:
+            lz.lz4Compress(bad, acceleration=0)
+        assert type(e.value).__name__ == "RangeError"
+
+
+def test_encoder_small_inputs_vs_oracle(lz, oracle):
+    rng = np.random.default_rng(21)
+    text = b"Hello Hello Hello Hello World, hello world; HELLO hello " * 40
+    inputs = [text[:n] for n in list(range(0, 40)) + [63, 64, 65, 100, 255, 256, 257, 511, 1000, 2000]]
+    inputs += [rng.integers(0, 4, size=n, dtype=np.uint8).tobytes() for n in (5, 17, 64, 300, 5000)]
+    inputs += [bytes(rng.integers(0, 256, size=n, dtype=np.uint8)) for n in (4, 8, 100, 3000)]
+    inputs += [open(os.path.join(GOLDEN_DIR, "test_input.txt"), "rb").read()]
+    for data in inputs:
+        for accel in (1, 2, 4, 7, 40, 1000):
+            got = lz.lz4Compress(data, acceleration=accel)
+            assert got == oracle.block_compress_fast(data, acceleration=accel), (len(data), accel)
+            assert lz.lz4Decompress(got, decompressedSize=len(data)) == data
+
+
+def test_encoder_corpus_blocks_vs_oracle_batch(codec, oracle):
+    """64 KiB blocks of every corpus class, all in one launch: bytes identical to the oracle,
+    then strict decode of those bytes gives the source back."""
+    import torch
+    nb = 96
+    data = corpus(nb)
+    src = torch.tensor(data, device="cuda")
+    for accel in (1, 3):
+        slots, sizes, status = codec.compress_blocks(src, 65536, acceleration=accel)
+        assert int(status.abs().sum()) == 0
+        h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+        for b in range(nb):
+            ref = oracle.block_compress_fast(data[b * 65536:(b + 1) * 65536].tobytes(), acceleration=accel)
+            assert int(h_sizes[b]) == len(ref), (b, accel)
+            assert h_slots[b, : len(ref)].tobytes() == ref, (b, accel)
+        out, out_len, st = codec.decompress_blocks(slots, sizes, 65536, strict=True)
+        assert int(st.abs().sum()) == 0
+        assert torch.equal(out.reshape(-1), src)
+
+
+def test_encoder_ragged_last_block_and_sizes(codec, oracle):
+    import torch
+    for block, total in ((65536, 65536 * 3 + 1234), (4096, 4096 * 5 + 3), (1 << 20, (1 << 20) + 77), (4 << 20, 5 << 20)):
+        nb = (total + block - 1) // block
+        data = corpus((total + 65535) // 65536)[:total]
+        src = torch.tensor(data, device="cuda")
+        slots, sizes, status = codec.compress_blocks(src, block)
+        assert int(status.abs().sum()) == 0
+        h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+        for b in range(nb):
+            ref = oracle.block_compress_fast(data[b * block:(b + 1) * block].tobytes())
+            assert h_slots[b, : int(h_sizes[b])].tobytes() == ref, (block, b)
+
+
+def test_encoder_with_dictionary_vs_oracle(lz, oracle):
+    text = corpus_block(3).tobytes()
+    d32k = text[:32768]
+    cases = [(bytes(range(64)), bytes(range(16, 48))), (d32k, text[30000:36000]), (d32k, text[40000:41000]),
+             (text[:70000], text[60000:65000]), (b"abcdefgh", b"abcdefghabcdefgh"), (d32k, b"ab"), (b"xy", text[:500])]
+    for d, data in cases:
+        got = lz.lz4Compress(data, dictionary=d)
+        assert got == oracle.block_compress_fast(data, dictionary=d), (len(d), len(data))
+
+
+# ---------------------------------------------------------------- frames
+
+@pytest.mark.parametrize("name", ["independent_70k", "dependent_70k", "small_default", "small_no_frame_crc",
+                                  "small_block_checksum", "small_content_size", "empty"])
+def test_lz4_cli_golden_frames_decode(lz, name):
+    frame, meta = golden_frame(name)
+    assert lz.lz4FrameDecode(frame) == ramp(meta["payload_len"])
+
+
+def test_skippable_and_concatenated_frames(lz):
+    frame, _ = golden_frame("small_default")
+    skippable = u32le(0x184D2A50) + u32le(4) + bytes([0xDE, 0xAD, 0xBE, 0xEF])
+    assert lz.lz4FrameDecode(skippable + frame) == ramp(1024)
+    assert lz.lz4FrameDecode(frame + skippable + frame) == ramp(1024) * 2
+
+
+def test_frame_decoder_error_matrix_vs_oracle(lz, oracle):
+    """Hand-built frames of test/frame/lz4_frame_decoder_test.dart:99-468."""
+    bf = lambda **kw: build_frame(xxh32=oracle.xxh32, **kw)  # noqa: E731
+    hello = b"Hello"
+    raw = [(hello, hello, True)]
+    one = [(b"A", b"A", True)]
+    assert lz.lz4FrameDecode(bf(flg=0x60, bd=0x40, blocks=raw)) == hello
+    assert lz.lz4FrameDecode(bf(flg=0x70, bd=0x40, blocks=raw)) == hello
+    assert lz.lz4FrameDecode(bf(flg=0x64, bd=0x40, blocks=raw, add_content_checksum=True)) == hello
+    dep = [(b"abcd", b"abcd", True), (bytes([0x00, 0x04, 0x00]), b"abcd", False)]
+    assert lz.lz4FrameDecode(bf(flg=0x40, bd=0x40, blocks=dep)) == b"abcdabcd"
+
+    good = bf(flg=0x60, bd=0x40, blocks=raw)
+    bad_hc = bytearray(good); bad_hc[6] ^= 0xFF
+    bad_bck = bytearray(bf(flg=0x70, bd=0x40, blocks=raw)); bad_bck[7 + 4 + 5] ^= 0xFF
+    bad_cck = bytearray(bf(flg=0x64, bd=0x40, blocks=raw, add_content_checksum=True)); bad_cck[-1] ^= 0xFF
+    big = bytes(65537)
+    frames = [bytes(bad_hc), bf(flg=0x20, bd=0x40, blocks=one), bf(flg=0x62, bd=0x40, blocks=one),
+              bf(flg=0x60, bd=0x41, blocks=one), bf(flg=0x60, bd=0x30, blocks=one),
+              bf(flg=0x61, bd=0x40, blocks=one, dict_id=0x12345678),
+              bf(flg=0x68, bd=0x40, blocks=raw, content_size=6), bytes(bad_bck), bytes(bad_cck),
+              bf(flg=0x60, bd=0x40, blocks=[(big, big, True)]), good[:-1], good[:9], b"\x01\x02\x03", b"\x01\x02\x03\x04",
+              # a corrupt compressed block followed by a structural error: the earlier block decides
+              bf(flg=0x60, bd=0x40, blocks=[(bytes([0x00, 0, 0]), b"", False)])[:-2],
+              bf(flg=0x60, bd=0x40, blocks=[(bytes([0x1F, 0x41, 1, 0]) + b"\xff" * 300 + b"\x00", b"", False)])]
+    for f in frames:
+        _same_error(lz, oracle, lambda: lz.lz4FrameDecode(f), lambda: oracle.frame_decode(f))
+    _same_error(lz, oracle, lambda: lz.lz4FrameDecode(good, maxOutputBytes=4),
+                lambda: oracle.frame_decode(good, max_output_bytes=4))
+    assert lz.lz4FrameDecode(good, maxOutputBytes=5) == hello
+
+
+def test_frame_dictionary_resolver_contract(lz, oracle):
+    for indep in (True, False):
+        flg = 0x40 | (0x20 if indep else 0) | 0x01
+        f = build_frame(flg=flg, bd=0x40, blocks=[(bytes([1, 2, 3]), bytes([1, 2, 3]), True)], dict_id=123,
+                        xxh32=oracle.xxh32)
+        with pytest.raises(lz.Lz4UnsupportedFeatureException):
+            lz.lz4FrameDecode(f)
+        with pytest.raises(lz.Lz4Exception) as e:
+            lz.lz4FrameDecode(f, dictionaryResolver=lambda i: None)
+        assert type(e.value) is lz.Lz4Exception and e.value.message == "Dictionary not found for ID: 123"
+        assert lz.lz4FrameDecode(f, dictionaryResolver=lambda i: b"" if i == 123 else None) == bytes([1, 2, 3])
+
+
+def test_frame_encode_bytes_equal_oracle(lz, oracle):
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    rng = np.random.default_rng(8)
+    datas = [b"", b"x", ramp(200000), corpus(5).tobytes()[:300001], rng.integers(0, 256, size=70000, dtype=np.uint8).tobytes()]
+    for data in datas:
+        for bs in (Lz4FrameBlockSize.k64KB, Lz4FrameBlockSize.k256KB):
+            for bck in (False, True):
+                for cck in (False, True):
+                    opts = Lz4FrameOptions(blockSize=bs, blockChecksum=bck, contentChecksum=cck,
+                                           contentSize=len(data) if cck else None, acceleration=1 + int(bck))
+                    ref = oracle.frame_encode(data, oracle.frame_options(
+                        block_size_id=bs.bdId, block_checksum=bck, content_checksum=cck,
+                        content_size=len(data) if cck else None, acceleration=1 + int(bck)))
+                    got = lz.lz4FrameEncodeWithOptions(data, options=opts)
+                    assert got == ref, (len(data), bs, bck, cck)
+                    assert lz.lz4FrameDecode(got) == data
+    with pytest.raises(lz.Lz4FormatException) as e:
+        lz.lz4FrameEncodeWithOptions(b"abc", options=Lz4FrameOptions(contentSize=4))
+    assert e.value.message == "contentSize does not match src length"
+    assert len(lz.lz4FrameEncodeWithOptions(ramp(1 << 20), options=Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB))) \
+        == golden()["encoder_sizes_repeating_1MiB"]["frame64k_fast"]
+
+
+def test_frame_4mib_blocks_with_checksums(lz, oracle):
+    """BASELINE configs[2] shape at test size: 4 MiB blocks + block/content checksums."""
+    from lz4_amd import Lz4FrameOptions
+    data = corpus(160).tobytes()  # 10 MiB -> 3 blocks
+    opts = Lz4FrameOptions(blockChecksum=True, contentChecksum=True)
+    got = lz.lz4FrameEncodeWithOptions(data, options=opts)
+    assert got == oracle.frame_encode(data, oracle.frame_options(block_checksum=True, content_checksum=True))
+    assert lz.lz4FrameDecode(got) == data
+
+
+def test_frame_dictionary_roundtrip_vs_oracle(lz, oracle):
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    text = corpus_block(3).tobytes()
+    d = text[:32768]
+    data = corpus(6, first=3).tobytes()
+    opts = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, dictId=0x12345678)
+    ref = oracle.frame_encode(data, oracle.frame_options(block_size_id=4, dict_id=0x12345678), dictionary=d)
+    got = lz.lz4FrameEncodeWithOptions(data, options=opts, dictionary=d)
+    assert got == ref
+    assert lz.lz4FrameDecode(got, dictionaryResolver=lambda i: d if i == 0x12345678 else None) == data
+    # HC-compressed, dictionary-primed frame from the oracle (BASELINE configs[4] decode side)
+    hc = oracle.frame_encode(data, oracle.frame_options(block_size_id=4, dict_id=7, compression=1,
+                                                        hc_max_search_depth=64), dictionary=d)
+    assert lz.lz4FrameDecode(hc, dictionaryResolver=lambda i: d) == data
+    # dependent-block frames from the oracle decode too
+    dep = oracle.frame_encode(data, oracle.frame_options(block_size_id=4, block_independence=False, compression=1,
+                                                         hc_max_search_depth=16))
+    assert lz.lz4FrameDecode(dep) == data
+
+
+def test_decode_real_lz4_cli_frames(lz, tmp_path):
+    """Frames written by the lz4 CLI of the image (v1.9.3): independent, linked, HC, 4 MiB blocks."""
+    cli = shutil.which("lz4") or "/opt/conda/bin/lz4"
+    if not os.path.exists(cli):
+        pytest.skip("lz4 CLI not present")
+    data = corpus(80).tobytes()
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    for flags in (["-B4"], ["-B4", "-BX", "--content-size"], ["-B7", "-BD"], ["-9", "-B5", "--no-frame-crc"],
+                  ["-B7", "-BX", "--content-size"]):
+        frame = subprocess.run([cli, "-c", "-f"] + flags + [str(src)], capture_output=True, check=True).stdout
+        assert lz.lz4FrameDecode(frame) == data, flags
+
+
+def test_decode_committed_lz4_cli_fixture(lz):
+    path = os.path.join(GOLDEN_DIR, "lz4cli_v193_corpus8_B4_BX.lz4")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    assert lz.lz4FrameDecode(open(path, "rb").read()) == corpus(8).tobytes()
+
+
+def test_our_frames_through_lz4_cli(lz, tmp_path):
+    """Interop check of test/interop/lz4_cli_decode_our_frames_test.dart: frames whose blocks obey
+    the LZ4 end-of-block rules (stored-raw blocks here) decode with the real CLI."""
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    cli = shutil.which("lz4") or "/opt/conda/bin/lz4"
+    if not os.path.exists(cli):
+        pytest.skip("lz4 CLI not present")
+    data = np.random.default_rng(77).integers(0, 256, size=200000, dtype=np.uint8).tobytes()
+    for opts in (Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB),
+                 Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockChecksum=True, contentChecksum=True,
+                                 contentSize=len(data))):
+        p = tmp_path / "f.lz4"
+        p.write_bytes(lz.lz4FrameEncodeWithOptions(data, options=opts))
+        out = subprocess.run([cli, "-d", "-c", str(p)], capture_output=True, check=True).stdout
+        assert out == data
+
+
+# ------------------------------------------------ size-independent properties
+
+def test_large_batch_roundtrip_and_sampled_oracle(codec, oracle):
+    """256 MiB of corpus (4096 blocks): every block status OK, decode(encode(x)) == x on the
+    device, and a strided sample of blocks is byte-identical to the oracle."""
+    import torch
+    nb = 4096
+    data = corpus(nb)
+    src = torch.tensor(data, device="cuda")
+    slots, sizes, status = codec.compress_blocks(src, 65536)
+    assert int(status.abs().sum()) == 0
+    out, out_len, st = codec.decompress_blocks(slots, sizes, 65536, strict=True)
+    assert int(st.abs().sum()) == 0
+    assert torch.equal(out.reshape(-1), src)
+    h_sizes = sizes.cpu().numpy()
+    for b in range(0, nb, 37):
+        ref = oracle.block_compress_fast(data[b * 65536:(b + 1) * 65536].tobytes())
+        assert int(h_sizes[b]) == len(ref)
+        assert slots[b, : len(ref)].cpu().numpy().tobytes() == ref
+    # second pass over the same scratch (table generations are reused, not cleared)
+    slots2, sizes2, _ = codec.compress_blocks(src, 65536)
+    assert torch.equal(sizes2, sizes)
+    assert torch.equal(slots2[7, : int(h_sizes[7])], slots[7, : int(h_sizes[7])])
+
+
+def test_device_frame_equals_host_frame(codec, lz, oracle):
+    import torch
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    data = corpus(40)
+    src = torch.tensor(data, device="cuda")
+    opts = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockChecksum=True, contentChecksum=True)
+    frame = codec.frame_encode(src, opts)
+    ref = oracle.frame_encode(data.tobytes(), oracle.frame_options(block_size_id=4, block_checksum=True,
+                                                                   content_checksum=True))
+    assert frame.cpu().numpy().tobytes() == ref
+
+
+def test_shard_assembly_equals_single_frame(codec, oracle):
+    """Two shards compressed separately + offsets from the gathered record sizes == one frame."""
+    import torch
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    data = corpus(32)
+    opts = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockChecksum=True)
+    ref = oracle.frame_encode(data.tobytes(), oracle.frame_options(block_size_id=4, block_checksum=True))
+    header = codec.frame_header(opts)
+    half = 16 * 65536
+    parts, recs = [], []
+    for r in range(2):
+        src = torch.tensor(data[r * half:(r + 1) * half], device="cuda")
+        rec = codec.shard_compress(src, opts).clone()
+        recs.append(rec)
+        parts.append(src)
+    allrec = torch.cat(recs).to(torch.int64)
+    offs = torch.cumsum(allrec, 0) - allrec
+    total = int(allrec.sum())
+    body = torch.zeros(total, dtype=torch.uint8, device="cuda")
+    for r in range(2):
+        codec.shard_compress(parts[r], opts)
+        base = int(offs[16 * r])
+        codec.shard_write(parts[r], opts, (offs[16 * r:16 * (r + 1)] - base).contiguous(), body[base:])
+    frame = header + body.cpu().numpy().tobytes() + u32le(0)
+    assert frame == ref

@@ -1,0 +1,153 @@
+"""CPU-only checks of the host layer: the C ABI library loads and exports every symbol the
+header declares, option validation mirrors the reference, and the product path refuses to
+run (loudly) without a GPU instead of falling back to anything."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lz4mi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lz4mi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lz4_amd import _native as N
+    lib = N.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(N.EXPORTS) == declared
+
+
+def test_status_strings_match_reference_messages():
+    from lz4_amd import _native as N
+    L = N.load()
+    expect = {
+        1: ("Lz4FormatException", "Unexpected end of input"),
+        2: ("Lz4FormatException", "Invalid LZ4 frame magic number"),
+        3: ("Lz4FormatException", "Reserved FLG bit is set"),
+        4: ("Lz4FormatException", "Reserved BD bits are set"),
+        5: ("Lz4FormatException", "Invalid block maximum size"),
+        6: ("Lz4FormatException", "Integer overflow"),
+        7: ("Lz4FormatException", "contentSize does not match src length"),
+        10: ("Lz4CorruptDataException", "Literal length exceeds output size"),
+        11: ("Lz4CorruptDataException", "Match length exceeds output size"),
+        12: ("Lz4CorruptDataException", "Trailing bytes after end of block"),
+        13: ("Lz4CorruptDataException", "Invalid match distance"),
+        14: ("Lz4CorruptDataException", "Header checksum mismatch"),
+        15: ("Lz4CorruptDataException", "Block size exceeds maximum"),
+        16: ("Lz4CorruptDataException", "Block checksum mismatch"),
+        17: ("Lz4CorruptDataException", "Content checksum mismatch"),
+        18: ("Lz4CorruptDataException", "Content size mismatch"),
+        30: ("Lz4OutputLimitException", "Output limit exceeded"),
+        40: ("Lz4UnsupportedFeatureException", "Unsupported LZ4 frame version"),
+        41: ("Lz4UnsupportedFeatureException", "Dictionary ID present but no dictionary resolver provided"),
+        50: ("Lz4Exception", "Dictionary not found for ID: "),
+    }
+    for code, (t, m) in expect.items():
+        assert L.lz4mi_status_type(code).decode() == t
+        assert L.lz4mi_status_message(code).decode() == m
+
+
+def test_product_and_oracle_agree_on_status_codes(oracle):
+    from lz4_amd import _native as N
+    L, R = N.load(), oracle.lib()
+    for code in list(range(0, 8)) + list(range(10, 21)) + [30, 40, 41, 50]:
+        assert L.lz4mi_status_message(code) == R.lz4ref_status_message(code)
+
+
+def test_compress_bound_and_frame_bound():
+    import ctypes as C
+    from lz4_amd import _native as N
+    L = N.load()
+    assert L.lz4mi_compress_bound(0) == 16
+    assert L.lz4mi_compress_bound(65536) == 65536 + 257 + 16
+    o = N.FrameOptions()
+    L.lz4mi_frame_options_default(C.byref(o))
+    assert (o.block_size_id, o.block_independence, o.acceleration, o.hc_max_search_depth) == (7, 1, 1, 64)
+    assert L.lz4mi_frame_bound(0, C.byref(o)) >= 15
+
+
+def test_frame_header_bytes_match_golden_frames():
+    """Header construction (host code, no GPU): same bytes as the lz4 CLI wrote."""
+    import ctypes as C
+    from lz4_amd import _native as N
+    from lz4_amd.api import _c_options
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions
+    from tests.helpers import golden_frame
+    L = N.load()
+    cases = {
+        "small_default": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, contentChecksum=True),
+        "small_no_frame_crc": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB),
+        "small_block_checksum": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockChecksum=True, contentChecksum=True),
+        "small_content_size": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, contentChecksum=True, contentSize=1024),
+        "independent_70k": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockChecksum=True, contentChecksum=True, contentSize=71680),
+        "dependent_70k": Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockIndependence=False, blockChecksum=True, contentChecksum=True, contentSize=71680),
+    }
+    for name, opts in cases.items():
+        frame, _ = golden_frame(name)
+        o = _c_options(opts)
+        buf = C.create_string_buffer(32)
+        n = C.c_size_t(0)
+        assert L.lz4mi_frame_header(C.byref(o), buf, 32, C.byref(n)) == 0
+        assert buf.raw[: n.value] == frame[: n.value], name
+
+
+def test_frame_decode_bound_walks_blocks():
+    import ctypes as C
+    from lz4_amd import _native as N
+    from tests.helpers import golden_frame
+    L = N.load()
+    frame, _ = golden_frame("independent_70k")
+    b = C.c_size_t(0)
+    buf = C.create_string_buffer(frame, len(frame))
+    assert L.lz4mi_frame_decode_bound(buf, len(frame), C.byref(b)) == 0
+    assert b.value == 2 * 65536
+
+
+def test_options_validation_mirrors_reference():
+    # lib/src/frame/lz4_frame_options.dart:89-99, lib/src/hc/lz4_hc_options.dart:13-15
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameOptions, Lz4HcOptions, RangeError
+    o = Lz4FrameOptions()
+    assert o.blockSize == Lz4FrameBlockSize.k4MB and o.blockIndependence and not o.blockChecksum
+    assert not o.contentChecksum and o.contentSize is None and o.dictId is None and o.acceleration == 1
+    assert [b.bdId for b in Lz4FrameBlockSize] == [4, 5, 6, 7]
+    assert [b.maxBytes for b in Lz4FrameBlockSize] == [65536, 262144, 1048576, 4194304]
+    for kw in (dict(acceleration=0), dict(contentSize=-1), dict(dictId=-1), dict(dictId=1 << 32)):
+        with pytest.raises(RangeError):
+            Lz4FrameOptions(**kw)
+    with pytest.raises(RangeError):
+        Lz4HcOptions(maxSearchDepth=0)
+    assert Lz4HcOptions().maxSearchDepth == 64
+
+
+def test_exception_string_form():
+    from lz4_amd import Lz4CorruptDataException, Lz4Exception
+    e = Lz4CorruptDataException("Invalid match distance")
+    assert isinstance(e, Lz4Exception) and str(e) == "Lz4CorruptDataException: Invalid match distance"
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import lz4_amd
+    with pytest.raises(lz4_amd.Lz4BackendError):
+        lz4_amd.lz4Compress(b"hello hello hello")
+    with pytest.raises(lz4_amd.Lz4BackendError):
+        lz4_amd.lz4FrameDecode(b"\x04\x22\x4d\x18\x60\x40\x82\x00\x00\x00\x00")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lz4_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "lz4ref" not in text and "oracle" not in text.lower(), os.path.join(dirpath, f)
