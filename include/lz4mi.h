@@ -74,6 +74,7 @@ typedef struct lz4mi_ctx lz4mi_ctx;
 int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **out);
 void lz4mi_ctx_destroy(lz4mi_ctx *ctx);
 int32_t lz4mi_ctx_synchronize(lz4mi_ctx *ctx);
+/* ctx == NULL: reason of the last failed lz4mi_ctx_create */
 const char *lz4mi_last_backend_error(lz4mi_ctx *ctx);
 /* nonzero when built with the HIP kernels for gfx950 (always, in this build) */
 int32_t lz4mi_version(void);

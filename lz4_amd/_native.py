@@ -65,6 +65,10 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        try:  # torch bundles its own HIP runtime; it must be the one this process uses
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise Lz4BackendError(
                 f"{LIB_PATH} is missing: build it with `make -C lz4_amd/csrc` "
@@ -146,8 +150,9 @@ class Context:
         h = C.c_void_p()
         st = L.lz4mi_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h))
         if st != OK:
+            why = L.lz4mi_last_backend_error(None).decode()
             raise Lz4BackendError(
-                f"lz4mi_ctx_create(device={device}) failed with status {st}: no usable MI355X / HIP runtime")
+                f"lz4mi_ctx_create(device={device}) failed with status {st}: no usable MI355X / HIP runtime ({why})")
         self.handle = h
         self.device = device
         self._L = L

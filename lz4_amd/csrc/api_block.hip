@@ -58,31 +58,43 @@ extern "C" size_t lz4mi_compress_bound(size_t n) { return bound(n); }
 
 enum { kCounterDecode = 0, kCounterEncode = 1, kCounterHc = 2, kNumCounters = 16 };
 
+static std::string g_create_error;  // reason of the last failed lz4mi_ctx_create
+
+static int32_t create_fail(lz4mi_ctx *c, hipError_t e, const char *what) {
+  g_create_error = std::string(what) + ": " + hipGetErrorString(e);
+  if (c) lz4mi_ctx_destroy(c);
+  return LZ4MI_BACKEND;
+}
+
 extern "C" int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **out) {
   if (!out) return LZ4MI_RANGE;
   *out = nullptr;
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return LZ4MI_BACKEND;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess) return create_fail(nullptr, e, "hipGetDeviceCount");
+  if (device < 0 || device >= count) {
+    g_create_error = "device ordinal out of range (" + std::to_string(count) + " devices visible)";
+    return LZ4MI_BACKEND;
+  }
   lz4mi_ctx *c = new lz4mi_ctx();
   c->device = device;
-  if (hipSetDevice(device) != hipSuccess) { delete c; return LZ4MI_BACKEND; }
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-    c->cu_count = prop.multiProcessorCount;
+  if ((e = hipSetDevice(device)) != hipSuccess) return create_fail(c, e, "hipSetDevice");
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    c->cu_count = cus;
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return LZ4MI_BACKEND; }
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+      return create_fail(c, e, "hipStreamCreateWithFlags");
     c->own_stream = true;
   }
-  if (hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t)) != hipSuccess) {
-    lz4mi_ctx_destroy(c);
-    return LZ4MI_BACKEND;
-  }
+  if ((e = hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t))) != hipSuccess)
+    return create_fail(c, e, "hipMalloc");
   uint32_t wpc = 16;  // resident encoder wavefronts per CU (one 256 KiB table each)
-  if (const char *e = getenv("LZ4MI_ENC_WAVES_PER_CU")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 32) wpc = (uint32_t)v;
+  if (const char *v = getenv("LZ4MI_ENC_WAVES_PER_CU")) {
+    int n = atoi(v);
+    if (n >= 1 && n <= 32) wpc = (uint32_t)n;
   }
   c->max_slots = (uint32_t)c->cu_count * wpc;
   *out = c;
@@ -109,7 +121,7 @@ extern "C" int32_t lz4mi_ctx_synchronize(lz4mi_ctx *c) {
   return LZ4MI_OK;
 }
 
-extern "C" const char *lz4mi_last_backend_error(lz4mi_ctx *c) { return c ? c->err.c_str() : ""; }
+extern "C" const char *lz4mi_last_backend_error(lz4mi_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 namespace lz4mi {
 

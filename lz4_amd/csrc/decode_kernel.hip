@@ -203,9 +203,7 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
   const uint8_t *prefix = a.dict;
   uint32_t prefix_len = a.dict_len;
   for (;;) {
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(counter, 1u);
-    b = uni(b);
+    const uint32_t b = next_block(counter, lane);
     if (b >= a.nblocks) break;
     const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
     uint32_t src_len = uni(block_src_len(a, b));

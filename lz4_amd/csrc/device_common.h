@@ -28,6 +28,15 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 
+// Work-queue pop for a persistent wavefront.  Every lane takes part in the atomic (lanes
+// other than 0 add zero) so that no per-lane branch sits in front of the cross-lane read:
+// with `if (lane == 0)` here the compiler may thread lanes 1..63 past the pop of the next
+// loop iteration, after which they would read a stale index forever.
+__device__ __forceinline__ uint32_t next_block(uint32_t *counter, uint32_t lane) {
+  uint32_t v = atomicAdd(counter, lane == 0 ? 1u : 0u);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
 // Unaligned little-endian accesses (gfx950 global memory handles any byte alignment).
 struct __attribute__((packed)) U32U { uint32_t v; };
 struct __attribute__((packed)) U64U { uint64_t v; };

@@ -16,7 +16,7 @@
 // table (position j and j+d hash the same bytes and j+d is inserted later), so
 // the interior re-hash (:139-145) touches min(length-4, d) positions.
 //
-// Table: 65536 x u32 per wavefront slot in HBM/L2, entry = generation<<23 | (pos+1);
+// Table: 65536 x u32 per wavefront slot in HBM/L2, entry = generation<<24 | (pos+1);
 // a stale generation reads as empty, so a slot is reused without clearing.
 // A shared dictionary is primed once into a read-only table consulted when the
 // slot entry is empty (dictionary positions are always smaller than block positions).
@@ -229,9 +229,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
   in.dict = a.dict;
   in.D = a.dict_len;
   for (;;) {
-    uint32_t b = 0;
-    if (lane == 0) b = atomicAdd(counter, 1u);
-    b = uni(b);
+    const uint32_t b = next_block(counter, lane);
     if (b >= a.nblocks) break;
     if (++gen > kGenMax) {  // generation wrapped: clear the slot
       for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(T + k) = make_uint4(0, 0, 0, 0);
