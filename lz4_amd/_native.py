@@ -13,7 +13,8 @@ from .exceptions import (Lz4BackendError, Lz4CorruptDataException, Lz4Exception,
                          Lz4OutputLimitException, Lz4UnsupportedFeatureException, RangeError)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblz4mi.so")
+# LZ4MI_LIB selects another build of the same ABI (e.g. the diagnostic liblz4mi_prof.so)
+LIB_PATH = os.environ.get("LZ4MI_LIB") or os.path.join(_HERE, "liblz4mi.so")
 
 OK = 0
 DICT_NOT_FOUND = 50

@@ -8,13 +8,22 @@
 // Layout: the token stream is parsed wave-uniformly out of a 512-byte register
 // window of the compressed block (two dwords per lane, fetched with one
 // coalesced load and read back with v_readlane), so the parse chain never
-// waits on memory.  Literal and match bytes are moved by all 64 lanes:
-// 16-byte aligned stores for long runs, a byte per lane for short ones, and a
-// modulo-period gather for matches that overlap their own output.
+// waits on memory.  Short literal runs are taken from that same register window
+// (ds_bpermute), and the most recent 8 KiB of output are mirrored in an LDS ring
+// per wavefront, so a short match whose source is recent is served from LDS: a
+// typical sequence then needs no memory round trip at all, only stores.
+// Long runs go memory to memory with 16-byte aligned stores (1 KiB per
+// wave-instruction); matches that overlap their own output replicate the period
+// with a modulo gather.
 #include "device_common.h"
 #include "kernels.h"
+#include "profile.h"
 
 namespace lz4mi {
+
+#ifdef LZ4MI_PROFILE
+__device__ unsigned long long g_dec_phase[PH_SLOTS];
+#endif
 
 struct InWindow {
   const uint8_t *al;   // 4-byte aligned base (src - mis)
@@ -123,16 +132,30 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   }
 }
 
+constexpr uint32_t kRing = 8192;   // bytes of recent output mirrored in LDS per wavefront
+constexpr uint32_t kShort = 256;   // copies up to this length go through the ring path
+
+// Byte at compressed offset pos + lane for lanes < n, straight from the register window.
+// Caller guarantees [pos, pos + n) lies inside the resident 512-byte window.
+__device__ __forceinline__ uint32_t win_lane_byte(const InWindow &w, uint32_t pos, uint32_t lane) {
+  uint32_t rel = pos + lane + w.mis - w.base;
+  uint32_t d = rel >> 2;
+  uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)w.w0);
+  uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)w.w1);
+  uint32_t word = (d & 64u) ? b : a;
+  return (word >> ((rel & 3u) * 8u)) & 0xffu;
+}
+
 // Decodes one block with the whole wave into dst[op_start ...).  `cap` is
 // decompressedSize (STRICT) or the ByteWriter maxLength minus the pre-filled prefix
 // (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
 // non-negative positions come from dst itself (earlier blocks of a linked frame),
 // negative positions from the tail of `prefix` (dictionary).  out_len = bytes written.
 template <bool STRICT, bool HAS_PREFIX>
-__device__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
-                                const uint64_t op_start, uint32_t cap, uint32_t back_limit,
-                                const uint8_t *__restrict__ prefix, uint32_t prefix_len, uint32_t lane,
-                                uint32_t &out_len) {
+__device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
+                                                const uint64_t op_start, uint32_t cap, uint32_t back_limit,
+                                                const uint8_t *__restrict__ prefix, uint32_t prefix_len,
+                                                lds_u8 *ring, uint32_t lane, uint32_t &out_len) {
   InWindow w;
   w.mis = (uint32_t)((uintptr_t)src & 3u);
   w.al = src - w.mis;
@@ -142,8 +165,11 @@ __device__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_le
   w.w0 = w.w1 = w.n0 = w.n1 = 0;
 
   uint32_t ip = 0, op = 0;  // op counts bytes written by this block
+  uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
   const uint32_t in_end = src_len;
   int32_t st = LZ4MI_OK;
+  uint8_t *const out = dst + op_start;
+  PH_DECL
 
   for (;;) {
     if (STRICT) {
@@ -157,17 +183,35 @@ __device__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_le
     }
     uint32_t token = win_byte(w, ip, lane);
     ip++;
-    uint64_t lit = token >> 4;
-    if (lit == 15) {
-      if (!read_ext(w, src, ip, in_end, lit, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+    uint64_t lit64 = token >> 4;
+    if (lit64 == 15) {
+      if (!read_ext(w, src, ip, in_end, lit64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
     }
-    if (STRICT && lit > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_LITERAL; break; }  // :33-35
-    if (lit != 0) {
-      if (lit > (uint64_t)(in_end - ip)) { st = LZ4MI_FORMAT_EOF; break; }  // readBytesView
-      if (!STRICT && lit > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; } // writer maxLength
-      wave_copy(dst + op_start + op, src + ip, (uint32_t)lit, lane);
-      ip += (uint32_t)lit;
-      op += (uint32_t)lit;
+    if (STRICT && lit64 > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_LITERAL; break; }  // :33-35
+    if (lit64 != 0) {
+      if (lit64 > (uint64_t)(in_end - ip)) { st = LZ4MI_FORMAT_EOF; break; }  // readBytesView
+      if (!STRICT && lit64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; } // writer maxLength
+      const uint32_t lit = (uint32_t)lit64;
+      PH(0);
+      if (lit <= kShort) {
+        const bool in_regs = ip + lit + w.mis <= w.base + 512u;  // ip itself is resident (token just read)
+        for (uint32_t k0 = 0; k0 < lit; k0 += kWave) {
+          uint32_t k = k0 + lane;
+          uint32_t v = in_regs ? win_lane_byte(w, ip + k0, lane) : (k < lit ? (uint32_t)src[ip + k] : 0u);
+          if (k < lit) {
+            out[op + k] = (uint8_t)v;
+            ring[(op + k) & (kRing - 1)] = (uint8_t)v;
+          }
+        }
+        if (op + lit > rlo + kRing) rlo = op + lit - kRing;
+        PH(1); PH_CNT(8); if (!in_regs) PH_CNT(12);
+      } else {
+        wave_copy(out + op, src + ip, lit, lane);
+        rlo = op + lit;  // ring holds nothing older than this
+        PH(2); PH_CNT(9);
+      }
+      ip += lit;
+      op += lit;
     }
     if (STRICT) {
       if (op == cap) {  // :42-48
@@ -181,24 +225,61 @@ __device__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_le
     uint32_t dist = win_byte(w, ip, lane);
     dist |= win_byte(w, ip + 1, lane) << 8;
     ip += 2;
-    uint64_t ml = (token & 15u) + 4u;
+    uint64_t ml64 = (token & 15u) + 4u;
     if ((token & 15u) == 15u) {
-      if (!read_ext(w, src, ip, in_end, ml, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+      if (!read_ext(w, src, ip, in_end, ml64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
     }
-    if (STRICT && ml > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_MATCH; break; }  // :61-63
+    if (STRICT && ml64 > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_MATCH; break; }  // :61-63
     // copyMatch: distance first (byte_writer.dart:97-99), then capacity (:104)
     if (dist == 0 || (uint64_t)dist > (uint64_t)op + back_limit) { st = LZ4MI_CORRUPT_DISTANCE; break; }
-    if (!STRICT && ml > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; }
-    copy_match<HAS_PREFIX>(dst, op_start + op, dist, (uint32_t)ml, prefix, prefix_len, lane);
-    op += (uint32_t)ml;
+    if (!STRICT && ml64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; }
+    const uint32_t ml = (uint32_t)ml64;
+    PH(0);
+    if (ml <= kShort) {
+      // byte-serial copy semantics (byte_writer.dart:116-118): source byte of output k is
+      // k mod dist bytes into the period that ends at op
+      const int32_t s = (int32_t)op - (int32_t)dist;
+      const int32_t ring_from = (int32_t)(op + ml > rlo + kRing ? op + ml - kRing : rlo);
+      const bool overlap = dist < ml;
+      uint32_t r = lane, step = kWave;
+      if (overlap) {
+        r = dist >= kWave ? lane : lane % dist;
+        step = dist > kWave ? kWave : kWave % dist;
+      }
+      for (uint32_t k = lane; k < ml; k += kWave) {
+        int32_t p = s + (int32_t)r;
+        uint32_t v;
+        if (p >= ring_from) {
+          v = ring[(uint32_t)p & (kRing - 1)];
+        } else {
+          int64_t ap = (int64_t)op_start + p;
+          v = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+        }
+        out[op + k] = (uint8_t)v;
+        ring[(op + k) & (kRing - 1)] = (uint8_t)v;
+        r += step;
+        if (overlap && r >= dist) r -= dist;
+      }
+      rlo = (uint32_t)ring_from;
+      if (s >= ring_from) { PH(3); PH_CNT(10); } else { PH(4); PH_CNT(11); }
+    } else {
+      copy_match<HAS_PREFIX>(dst, op_start + op, dist, ml, prefix, prefix_len, lane);
+      rlo = op + ml;
+      PH(5); PH_CNT(13);
+    }
+    op += ml;
   }
+  PH(0);
+  PH_FLUSH(g_dec_phase, lane);
   out_len = op;
   return st;
 }
 
 template <bool STRICT, bool HAS_PREFIX>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
   const uint32_t lane = lane_id();
+  lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
   uint32_t prefix_len = a.dict_len;
@@ -210,8 +291,8 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
     uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;
-    int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, lane,
-                                                  out_len);
+    int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, ring,
+                                                  lane, out_len);
     if (lane == 0) {
       a.out_len[b] = out_len;
       a.status[b] = st;
@@ -224,6 +305,8 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
 // (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
 // serial, so one wavefront walks the blocks in order over one contiguous output.
 __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing];
+  lds_u8 *ring = (lds_u8 *)s_ring;
   const uint32_t lane = lane_id();
   uint64_t start = 0;
   uint32_t b = 0;
@@ -238,7 +321,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, lane,
+      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, ring, lane,
                                      produced);
     }
     if (lane == 0) {
@@ -253,6 +336,16 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     c.status[k] = LZ4MI_OK;
   }
 }
+
+#ifdef LZ4MI_PROFILE
+extern "C" void lz4mi_debug_dec_phases(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_phase), sizeof(unsigned long long) * PH_SLOTS);
+  if (reset) {
+    unsigned long long z[PH_SLOTS] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_phase), z, sizeof z);
+  }
+}
+#endif
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
   if (!c.nblocks) return;

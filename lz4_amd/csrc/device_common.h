@@ -47,23 +47,49 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t *p) { return ((const U64U
 __device__ __forceinline__ U128U ld128(const uint8_t *p) { return *(const U128U *)p; }
 __device__ __forceinline__ void st128(uint8_t *p, U128U v) { *(U128U *)p = v; }
 
+// LDS-typed pointers keep ring accesses on ds_read/ds_write (a generic pointer merged with a
+// global one would turn them into flat accesses).
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x4 lds_u128;
+
 // Wave-cooperative copy of n bytes between non-overlapping ranges.
 // Destination is brought to 16-byte alignment first so the body uses aligned
-// 16-byte stores (1 KiB per wave-instruction); loads may be unaligned.
+// 16-byte stores (1 KiB per wave-instruction); loads may be unaligned.  Every load of a
+// group is issued before the first store that depends on it, 4 KiB per group, so a copy
+// costs one memory round trip per 4 KiB instead of one per instruction.
 __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
   if (n <= kWave) {
     if (lane < n) dst[lane] = src[lane];
     return;
   }
-  uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;
-  if (lane < head) dst[lane] = src[lane];
-  dst += head;
-  src += head;
-  n -= head;
-  uint32_t body = n & ~15u;
-  for (uint32_t off = lane * 16; off < body; off += kWave * 16) st128(dst + off, ld128(src + off));
-  uint32_t tail = n - body;
-  if (lane < tail) dst[body + lane] = src[body + lane];
+  const uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;
+  const uint32_t body = (n - head) & ~15u;
+  const uint32_t tail = n - head - body;
+  const uint8_t *s = src + head;
+  uint8_t *d = dst + head;
+  uint8_t hb = 0, tb = 0;
+  if (lane < head) hb = src[lane];
+  if (lane < tail) tb = s[body + lane];
+  uint32_t off = lane * 16;
+  for (; off + 3 * 1024 < body; off += 4096) {
+    U128U a = ld128(s + off), b = ld128(s + off + 1024), c = ld128(s + off + 2048), e = ld128(s + off + 3072);
+    st128(d + off, a);
+    st128(d + off + 1024, b);
+    st128(d + off + 2048, c);
+    st128(d + off + 3072, e);
+  }
+  U128U r0 = {0, 0, 0, 0}, r1 = r0, r2 = r0;
+  const bool h0 = off < body, h1 = off + 1024 < body, h2 = off + 2048 < body;
+  if (h0) r0 = ld128(s + off);
+  if (h1) r1 = ld128(s + off + 1024);
+  if (h2) r2 = ld128(s + off + 2048);
+  if (lane < head) dst[lane] = hb;
+  if (lane < tail) d[body + lane] = tb;
+  if (h0) st128(d + off, r0);
+  if (h1) st128(d + off + 1024, r1);
+  if (h2) st128(d + off + 2048, r2);
 }
 
 // xxHash32 constants (lib/src/xxhash/xxh32.dart:3-7).

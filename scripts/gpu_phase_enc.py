@@ -1,0 +1,28 @@
+"""Encoder phase breakdown with the diagnostic build (LZ4MI_LIB=lz4_amd/liblz4mi_prof.so)."""
+import ctypes as C, sys
+sys.path.insert(0, '.')
+import numpy as np, torch
+from lz4_amd import _native as N
+from lz4_amd.device import DeviceCodec
+from tools.corpus import corpus_block
+codec = DeviceCodec(0)
+L = N.load()
+NB = 1024
+names = ['0 sched+valid', '1 ld32+table gather', '2 collision loop', '3 ref check+tbl write', '4 backward', '5 forward',
+         '6 emit', '7 rehash', '8 #chunks', '9 #matches', '10 tail literals']
+for cls in [int(a) for a in sys.argv[1:]] or [5, 3, 1]:
+    blocks = [corpus_block(cls + 8 * k) for k in range(64)]
+    src = torch.from_numpy(np.concatenate([blocks[k % 64] for k in range(NB)])).cuda()
+    codec.compress_blocks(src, 65536); torch.cuda.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    L.lz4mi_debug_enc_phases(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); codec.compress_blocks(src, 65536); e1.record(); torch.cuda.synchronize()
+    L.lz4mi_debug_enc_phases(buf, 1)
+    v = list(buf)
+    print(f'class {cls}: {e0.elapsed_time(e1):.3f} ms for {NB} blocks', flush=True)
+    for i, nm in enumerate(names):
+        if i in (8, 9):
+            print(f'   {nm:28s} {v[i] / NB:10.1f} per block')
+        else:
+            print(f'   {nm:28s} {v[i] / NB / 100:10.1f} us per block (100 MHz ticks)')
