@@ -20,8 +20,7 @@
 // a stale generation reads as empty, so a slot is reused without clearing.
 // A shared dictionary is primed once into a read-only table consulted when the
 // slot entry is empty (dictionary positions are always smaller than block positions).
-#include "device_common.h"
-#include "kernels.h"
+#include "encode_common.h"
 #include "profile.h"
 
 namespace lz4mi {
@@ -29,49 +28,6 @@ namespace lz4mi {
 #ifdef LZ4MI_PROFILE
 __device__ unsigned long long g_enc_phase[PH_SLOTS];
 #endif
-
-struct EncIn {
-  const uint8_t *dict;  // last <=65535 dictionary bytes (positions [0, D))
-  const uint8_t *src;   // block bytes (positions [D, total))
-  uint32_t D;
-  uint32_t total;
-};
-
-template <bool HAS_DICT>
-__device__ __forceinline__ uint32_t in_byte(const EncIn &in, uint32_t pos) {
-  if (HAS_DICT && pos < in.D) return in.dict[pos];
-  return in.src[pos - in.D];
-}
-
-template <bool HAS_DICT>
-__device__ __forceinline__ uint32_t in_ld32(const EncIn &in, uint32_t pos) {
-  if (!HAS_DICT) return ld32(in.src + pos);
-  if (pos >= in.D) return ld32(in.src + (pos - in.D));
-  if (pos + 4 <= in.D) return ld32(in.dict + pos);
-  uint32_t v = 0;
-  for (uint32_t k = 0; k < 4; k++) v |= in_byte<true>(in, pos + k) << (8 * k);
-  return v;
-}
-
-__device__ __forceinline__ uint32_t hash16(uint32_t seq) { return (seq * 2654435761u) >> 16; }
-
-__device__ __forceinline__ uint32_t sched_next(uint32_t o, uint32_t sh) {
-  return o < 0x40000000u ? o + 1u + (o >> sh) : o;
-}
-
-__device__ __forceinline__ uint32_t tbl_load(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void tbl_max(uint32_t *p, uint32_t v) {
-  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// 255-run length extension (:216-223): q bytes of 255 then the remainder.
-__device__ __forceinline__ uint32_t emit_len(uint8_t *out, uint32_t op, uint32_t v, uint32_t lane) {
-  uint32_t q = v / 255u, r = v - q * 255u;
-  for (uint32_t k = lane; k <= q; k += kWave) out[op + k] = k < q ? (uint8_t)255 : (uint8_t)r;
-  return op + q + 1;
-}
 
 // ---------------------------------------------------------------- input window
 // A 4 KiB ring of the block's bytes around the current anchor lives in LDS (one ring per

@@ -478,3 +478,58 @@ def test_shard_assembly_equals_single_frame(codec, oracle):
         codec.shard_write(parts[r], opts, (offs[16 * r:16 * (r + 1)] - base).contiguous(), body[base:])
     frame = header + body.cpu().numpy().tobytes() + u32le(0)
     assert frame == ref
+
+
+# ------------------------------------------------------------------ HC encoder
+
+def test_hc_encoder_known_answers_and_contracts(lz, oracle):
+    from lz4_amd import Lz4CompressionLevel, Lz4HcOptions
+    hc = Lz4CompressionLevel.hc
+    assert lz.lz4Compress(b"", level=hc) == b""
+    assert lz.lz4Compress(b"A" * 256, level=hc) == bytes([0x1F, 0x41, 0x01, 0x00, 0xEC])
+    assert len(lz.lz4Compress(ramp(1 << 20), level=hc)) == golden()["encoder_sizes_repeating_1MiB"]["block_hc"]
+    a64k = b"A" * 65536
+    assert len(lz.lz4Compress(a64k, level=hc)) <= len(lz.lz4Compress(a64k))  # test/hc/...:33-42
+    rng = np.random.default_rng(31)
+    text = b"Hello Hello Hello Hello World, hello world; HELLO hello " * 60
+    inputs = [text[:n] for n in (1, 3, 4, 5, 17, 100, 1000, 3000)]
+    inputs += [rng.integers(0, 4, size=n, dtype=np.uint8).tobytes() for n in (64, 700, 5000)]
+    inputs += [bytes(rng.integers(0, 256, size=2000, dtype=np.uint8)), ramp(5000), b"ab" * 3000]
+    for data in inputs:
+        for depth in (1, 4, 64):
+            got = lz.lz4Compress(data, level=hc, hcOptions=Lz4HcOptions(maxSearchDepth=depth))
+            assert got == oracle.block_compress_hc(data, max_search_depth=depth), (len(data), depth)
+            assert lz.lz4Decompress(got, decompressedSize=len(data)) == data
+
+
+def test_hc_encoder_corpus_blocks_vs_oracle(codec, oracle):
+    import torch
+    nb = 16
+    data = corpus(nb)
+    src = torch.tensor(data, device="cuda")
+    slots, sizes, status = codec.compress_blocks(src, 65536, hc_depth=64)
+    assert int(status.abs().sum()) == 0
+    h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+    for b in range(nb):
+        ref = oracle.block_compress_hc(data[b * 65536:(b + 1) * 65536].tobytes(), max_search_depth=64)
+        assert h_slots[b, : int(h_sizes[b])].tobytes() == ref, b
+    out, out_len, st = codec.decompress_blocks(slots, sizes, 65536, strict=True)
+    assert int(st.abs().sum()) == 0 and torch.equal(out.reshape(-1), src)
+
+
+def test_hc_frame_with_dictionary_vs_oracle(lz, oracle):
+    """BASELINE configs[4] at test size: LZ4HC (depth 64) frame, 64 KiB blocks, dictId + 32 KiB dictionary."""
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameCompression, Lz4FrameOptions, Lz4HcOptions
+    text = corpus_block(3).tobytes()
+    d = text[:32768]
+    data = corpus(6, first=2).tobytes()
+    opts = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, dictId=0x12345678, compression=Lz4FrameCompression.hc,
+                           hcOptions=Lz4HcOptions(maxSearchDepth=64))
+    ref = oracle.frame_encode(data, oracle.frame_options(block_size_id=4, dict_id=0x12345678, compression=1,
+                                                         hc_max_search_depth=64), dictionary=d)
+    got = lz.lz4FrameEncodeWithOptions(data, options=opts, dictionary=d)
+    assert got == ref
+    assert lz.lz4FrameDecode(got, dictionaryResolver=lambda i: d) == data
+    assert len(lz.lz4FrameEncodeWithOptions(ramp(1 << 20), options=Lz4FrameOptions(
+        blockSize=Lz4FrameBlockSize.k64KB, compression=Lz4FrameCompression.hc))) \
+        == golden()["encoder_sizes_repeating_1MiB"]["frame64k_hc"]
