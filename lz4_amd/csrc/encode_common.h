@@ -45,6 +45,29 @@ __device__ __forceinline__ void tbl_max(uint32_t *p, uint32_t v) {
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Lanes of one wave-instruction that hold the same 16-bit hash as this lane (among `vmask`).
+__device__ __forceinline__ uint64_t same_hash_lanes(uint32_t h, uint64_t vmask) {
+  uint64_t same = vmask;
+  for (uint32_t bit = 0; bit < 16; bit++) {
+    bool set = (h >> bit) & 1u;
+    uint64_t m = __ballot(set);
+    same &= set ? m : ~m;
+  }
+  return same;
+}
+
+// Table insert for up to 64 ascending positions at once.  Every insert the encoder makes is at
+// a larger position than the bucket holds, and wave-instructions of one wavefront reach memory
+// in order, so a plain store is enough once the lanes of THIS instruction that share a bucket
+// have been reduced to the last one (largest position).  Plain stores stay in the XCD's L2;
+// device-scope atomics would execute at the memory side and evict the line.
+__device__ __forceinline__ void tbl_insert(uint32_t *T, uint32_t h, uint32_t v, bool valid, uint32_t lane) {
+  const uint64_t vmask = __ballot(valid);
+  const uint64_t same = same_hash_lanes(h, vmask);
+  const uint64_t later = same & ~((2ull << lane) - 1ull);
+  if (valid && !later) T[h] = v;
+}
+
 // 255-run length extension (:216-223): q bytes of 255 then the remainder.
 __device__ __forceinline__ uint32_t emit_len(uint8_t *out, uint32_t op, uint32_t v, uint32_t lane) {
   uint32_t q = v / 255u, r = v - q * 255u;

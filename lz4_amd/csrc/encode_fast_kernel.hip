@@ -69,15 +69,23 @@ __device__ __forceinline__ void win_commit(Win &w, uint32_t lane) {
   w.pending = false;
 }
 
-// Makes [s, s + 1 KiB) resident (clipped to the block) and keeps one segment in flight.
+// Run start: makes [s, s + 256) resident (clipped to the block).  Normally the ring is already
+// further ahead and nothing happens here; the in-flight segment is only waited for when needed.
 __device__ __forceinline__ void win_prepare(Win &w, uint32_t s, uint32_t lane) {
+  if (s >= w.lo && s <= w.hi && (w.hi >= s + 256 || w.hi >= w.n)) return;
   if (w.pending) win_commit(w, lane);
   if (s < w.lo || s > w.hi) w.lo = w.hi = s & ~(kSeg - 1);  // jumped out of the ring
-  while (w.hi < s + kSeg && w.hi < w.n) {
+  while (w.hi < s + 256 && w.hi < w.n) {
     win_issue(w, w.hi, lane);
     win_commit(w, lane);
   }
-  if (w.hi < w.n && w.hi < s + 3 * kSeg) win_issue(w, w.hi, lane);
+}
+
+// Called right after a point where the wavefront has waited on memory anyway: lands the
+// segment that was in flight and requests the next one, keeping the ring ~2 KiB ahead of s.
+__device__ __forceinline__ void win_service(Win &w, uint32_t s, uint32_t lane) {
+  if (w.pending) win_commit(w, lane);
+  if (w.hi < w.n && w.hi < s + 2 * kSeg) win_issue(w, w.hi, lane);  // keeps lo <= s - 1 KiB after it lands
 }
 
 __device__ __forceinline__ bool win_has(const Win &w, uint32_t s, uint32_t len) {
@@ -109,11 +117,11 @@ __device__ __forceinline__ uint32_t rd8(const EncIn &in, const Win &w, uint32_t 
 template <bool HAS_DICT>
 __device__ __forceinline__ uint32_t eq8(const EncIn &in, const Win &w, uint32_t p, uint32_t q, uint32_t total) {
   uint32_t avail = p < total ? (total - p < 8 ? total - p : 8u) : 0u;
-  if (avail == 8) {
-    uint32_t x0 = rd32<HAS_DICT>(in, w, p) ^ rd32<HAS_DICT>(in, w, q);
-    if (x0) return (uint32_t)__builtin_ctz(x0) >> 3;
-    uint32_t x1 = rd32<HAS_DICT>(in, w, p + 4) ^ rd32<HAS_DICT>(in, w, q + 4);
-    return x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u;
+  if (avail == 8) {  // all four reads are issued before the first compare: one round trip
+    uint32_t a0 = rd32<HAS_DICT>(in, w, p), b0 = rd32<HAS_DICT>(in, w, q);
+    uint32_t a1 = rd32<HAS_DICT>(in, w, p + 4), b1 = rd32<HAS_DICT>(in, w, q + 4);
+    uint32_t x0 = a0 ^ b0, x1 = a1 ^ b1;
+    return x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : (x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3) : 8u);
   }
   uint32_t eq = 0;
   for (uint32_t k = 0; k < avail; k++) {
@@ -183,7 +191,11 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         PH(1);
         // Earlier probes of this chunk that land in the same bucket act as the table entry
         // (:99-100 in program order): the nearest earlier lane with an equal hash wins.
+#ifdef LZ4MI_ABL_NOCOLL
+        if (false) {
+#else
         if (nvalid <= 12) {
+#endif
           for (uint32_t j = 0; j + 1 < nvalid; j++) {
             uint32_t hj = rdlane(h, j);
             if (ballot(valid && lane > j && h == hj)) {
@@ -191,7 +203,11 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
               if (valid && lane > j && h == hj) ref = (int32_t)ij;
             }
           }
+#ifdef LZ4MI_ABL_NOCOLL
+        } else if (false) {
+#else
         } else {
+#endif
           uint64_t peers = vmask & ((1ull << lane) - 1ull);
           for (uint32_t bit = 0; bit < 16; bit++) {
             bool set = (h >> bit) & 1u;
@@ -208,6 +224,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         if (valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu)  // :102-103
           hit = rd32<HAS_DICT>(in, w, (uint32_t)ref) == seq;
         uint64_t hm = ballot(hit);
+        win_service(w, anchor - D, lane);
         uint32_t K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
         if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe up to the hit
         PH(3);
@@ -262,6 +279,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           PH(5);
           // _writeSequence :172-200
           const uint32_t m4 = ml - 4;
+#ifndef LZ4MI_ABL_NOEMIT
           if (lane == 0) out[op] = (uint8_t)(((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u));
           op++;
           if (lit >= 15) op = emit_len(out, op, lit - 15, lane);
@@ -279,16 +297,23 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           }
           op += 2;
           if (m4 >= 15) op = emit_len(out, op, m4 - 15, lane);
+#endif
           anchor = ms + ml;  // :132-133
           matched = true;
           PH(6);
+#ifndef LZ4MI_ABL_NOREHASH
           if (anchor + 4 <= total) {  // :135-145 interior re-hash, last `dist` positions only
             uint32_t hi = anchor - 4;
             uint32_t lo = ms + 1;
             if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
-            for (uint32_t j = lo + lane; j <= hi; j += kWave)
-              tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
+            for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
+              const uint32_t j = j0 + lane;
+              const bool live = j <= hi;
+              uint32_t hj = live ? hash16(rd32<HAS_DICT>(in, w, j)) : 0u;
+              if (live) tbl_max(T + hj, gtag | (j + 1));
+            }
           }
+#endif
           PH(7);
           break;
         }
