@@ -38,8 +38,11 @@ __device__ __forceinline__ uint32_t sched_next(uint32_t o, uint32_t sh) {
   return o < 0x40000000u ? o + 1u + (o >> sh) : o;
 }
 
+// A table slot is only ever touched by the one wavefront that owns it, so lookups need no wider
+// scope than the workgroup: the load is served by the XCD's L2, where the wavefront's own
+// atomic-max inserts were performed (an agent-scope load would go past L2 to memory every time).
 __device__ __forceinline__ uint32_t tbl_load(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void tbl_max(uint32_t *p, uint32_t v) {
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

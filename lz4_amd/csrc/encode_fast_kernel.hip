@@ -30,86 +30,87 @@ __device__ unsigned long long g_enc_phase[PH_SLOTS];
 #endif
 
 // ---------------------------------------------------------------- input window
-// A 4 KiB ring of the block's bytes around the current anchor lives in LDS (one ring per
-// wavefront).  Probe reads near the anchor, the anchor side of match extension, literal
-// copies and the interior re-hash are served from it (LDS latency) instead of L2/HBM round
-// trips; the next 1 KiB segment is fetched into registers one run ahead and written to the
-// ring at the start of the following run.
-constexpr uint32_t kWinBytes = 4096, kSeg = 1024;
+// An 8 KiB ring of the block's bytes around the current anchor lives in LDS (one ring per
+// wavefront): probe reads, reference checks, match extension, literal bytes and the interior
+// re-hash of the common case (reference closer than ~6 KiB, match shorter than ~256 bytes) are
+// LDS reads.  That matters because vector-memory operations of a wavefront complete in issue
+// order: a global load issued after table atomics or output stores cannot return before those
+// have drained (~600-950 cycles each), whereas LDS reads are independent of them.  With the
+// ring, one sequence costs a single vector-memory wait (the hash-table gather of its probes);
+// everything written for a sequence (output bytes, table inserts) is issued after the last
+// read of that sequence.
+// The first 16 bytes of the ring are mirrored behind its end so that an unaligned 4- or 8-byte
+// read never has to be split at the wrap.
+#ifndef LZ4MI_WIN
+#define LZ4MI_WIN 8192
+#endif
+constexpr uint32_t kWinBytes = LZ4MI_WIN, kWinMask = kWinBytes - 1, kSeg = 1024, kWinPad = 16;
+constexpr uint32_t kLead = 640;  // an iteration may read ring bytes up to anchor + kLead
+
+struct __attribute__((packed)) P32 { uint32_t v; };
+struct __attribute__((packed)) P64 { uint64_t v; };
+typedef const __attribute__((address_space(3))) P32 lds_p32;
+typedef const __attribute__((address_space(3))) P64 lds_p64;
 
 struct Win {
-  lds_u8 *lds;         // this wavefront's ring (16-byte aligned)
+  lds_u8 *lds;         // this wavefront's ring (16-byte aligned, kWinBytes + kWinPad bytes)
   const uint8_t *src;  // block bytes
-  uint32_t n;          // block length
-  uint32_t lo, hi;     // ring holds block offsets [lo, hi); hi may overshoot n (zero padded)
-  uint32_t pend_pos;
-  bool pending;
-  U128U pend;
+  uint32_t n;          // block length (>= 4)
+  uint32_t lo, hi;     // ring holds block offsets [lo, hi), both multiples of kSeg; bytes at or past n read as zero
 };
 
-__device__ __forceinline__ void win_issue(Win &w, uint32_t pos, uint32_t lane) {
-  uint32_t o = pos + 16 * lane;
+// Ring reads by block offset (the caller guarantees residency).
+__device__ __forceinline__ uint32_t w32(const Win &w, uint32_t s) { return ((lds_p32 *)(w.lds + (s & kWinMask)))->v; }
+__device__ __forceinline__ uint64_t w64(const Win &w, uint32_t s) { return ((lds_p64 *)(w.lds + (s & kWinMask)))->v; }
+__device__ __forceinline__ uint32_t w8(const Win &w, uint32_t s) { return w.lds[s & kWinMask]; }
+
+// 16 bytes per lane of the 1 KiB segment at block offset pos (zero past the end of the block).
+__device__ __forceinline__ u32x4 seg_load(const Win &w, uint32_t pos, uint32_t lane) {
+  const uint32_t o = pos + 16 * lane;
+  u32x4 v = {0, 0, 0, 0};
   if (o + 16 <= w.n) {
-    w.pend = ld128(w.src + o);
-  } else {  // last segment of the block: byte-wise, zero padded
-    uint32_t v[4] = {0, 0, 0, 0};
-    for (uint32_t k = 0; k < 16; k++)
-      if (o + k < w.n) v[k >> 2] |= (uint32_t)w.src[o + k] << (8 * (k & 3));
-    w.pend = U128U{v[0], v[1], v[2], v[3]};
+    U128U t = ld128(w.src + o);
+    v = u32x4{t.a, t.b, t.c, t.d};
+  } else if (o < w.n) {  // the block's last, ragged 16 bytes: whole dwords, then one shifted out of the final dword
+    const uint32_t last = ld32(w.src + w.n - 4);
+    uint32_t t[4];
+    for (uint32_t k = 0; k < 4; k++) {
+      const uint32_t q = o + 4 * k;
+      t[k] = q + 4 <= w.n ? ld32(w.src + q) : (q < w.n ? last >> (8 * (q + 4 - w.n)) : 0u);
+    }
+    v = u32x4{t[0], t[1], t[2], t[3]};
   }
-  w.pend_pos = pos;
-  w.pending = true;
+  return v;
 }
 
-__device__ __forceinline__ void win_commit(Win &w, uint32_t lane) {
-  *(lds_u128 *)(w.lds + ((w.pend_pos + 16 * lane) & (kWinBytes - 1))) =
-      u32x4{w.pend.a, w.pend.b, w.pend.c, w.pend.d};
-  w.hi = w.pend_pos + kSeg;
+__device__ __forceinline__ void seg_store(Win &w, uint32_t pos, u32x4 v, uint32_t lane) {
+  *(lds_u128 *)(w.lds + ((pos + 16 * lane) & kWinMask)) = v;
+  if ((pos & kWinMask) == 0 && lane == 0) *(lds_u128 *)(w.lds + kWinBytes) = v;  // wrap mirror
+  w.hi = pos + kSeg;
   if (w.hi - w.lo > kWinBytes) w.lo = w.hi - kWinBytes;
-  w.pending = false;
 }
 
-// Run start: makes [s, s + 256) resident (clipped to the block).  Normally the ring is already
-// further ahead and nothing happens here; the in-flight segment is only waited for when needed.
-__device__ __forceinline__ void win_prepare(Win &w, uint32_t s, uint32_t lane) {
-  if (s >= w.lo && s <= w.hi && (w.hi >= s + 256 || w.hi >= w.n)) return;
-  if (w.pending) win_commit(w, lane);
-  if (s < w.lo || s > w.hi) w.lo = w.hi = s & ~(kSeg - 1);  // jumped out of the ring
-  while (w.hi < s + 256 && w.hi < w.n) {
-    win_issue(w, w.hi, lane);
-    win_commit(w, lane);
-  }
-}
-
-// Called right after a point where the wavefront has waited on memory anyway: lands the
-// segment that was in flight and requests the next one, keeping the ring ~2 KiB ahead of s.
-__device__ __forceinline__ void win_service(Win &w, uint32_t s, uint32_t lane) {
-  if (w.pending) win_commit(w, lane);
-  if (w.hi < w.n && w.hi < s + 2 * kSeg) win_issue(w, w.hi, lane);  // keeps lo <= s - 1 KiB after it lands
+// Synchronous fill: makes [s, need) resident (need <= s + kLead, clipped to the block by the caller).
+__device__ __forceinline__ void win_fill(Win &w, uint32_t s, uint32_t need, uint32_t lane) {
+  if (s < w.lo || s > w.hi) w.lo = w.hi = s & ~(kSeg - 1);  // the anchor jumped out of the ring
+  while (w.hi < need) seg_store(w, w.hi, seg_load(w, w.hi, lane), lane);
 }
 
 __device__ __forceinline__ bool win_has(const Win &w, uint32_t s, uint32_t len) {
-  uint32_t top = w.hi < w.n ? w.hi : w.n;
-  return s >= w.lo && s + len <= top;
+  return s >= w.lo && s + len <= w.hi && s + len <= w.n;
 }
-__device__ __forceinline__ uint32_t win_ld32(const Win &w, uint32_t s) {
-  uint32_t r = s & (kWinBytes - 1), a0 = r & ~3u, a1 = (a0 + 4) & (kWinBytes - 1);
-  uint32_t lo = *(const lds_u32 *)(w.lds + a0), hi = *(const lds_u32 *)(w.lds + a1);
-  return __builtin_amdgcn_alignbyte(hi, lo, r & 3u);
-}
-__device__ __forceinline__ uint32_t win_u8(const Win &w, uint32_t s) { return w.lds[s & (kWinBytes - 1)]; }
 
 // position-based reads of dict||src: ring when resident, memory otherwise
 template <bool HAS_DICT>
 __device__ __forceinline__ uint32_t rd32(const EncIn &in, const Win &w, uint32_t pos) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
-  if (pos >= D && win_has(w, pos - D, 4)) return win_ld32(w, pos - D);
+  if (pos >= D && win_has(w, pos - D, 4)) return w32(w, pos - D);
   return in_ld32<HAS_DICT>(in, pos);
 }
 template <bool HAS_DICT>
 __device__ __forceinline__ uint32_t rd8(const EncIn &in, const Win &w, uint32_t pos) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
-  if (pos >= D && win_has(w, pos - D, 1)) return win_u8(w, pos - D);
+  if (pos >= D && win_has(w, pos - D, 1)) return w8(w, pos - D);
   return in_byte<HAS_DICT>(in, pos);
 }
 
@@ -131,6 +132,28 @@ __device__ __forceinline__ uint32_t eq8(const EncIn &in, const Win &w, uint32_t 
   return eq;
 }
 
+// Equal leading bytes (0..16) of the 16 bytes at p and q (q < p), straight from memory: both loads
+// are issued before the compare.  Falls back to the generic path near the block end and for
+// references that start inside the dictionary.
+template <bool HAS_DICT>
+__device__ __forceinline__ uint32_t eq16g(const EncIn &in, const Win &w, uint32_t p, uint32_t q, uint32_t total) {
+  const uint32_t D = HAS_DICT ? in.D : 0u;
+  if (p + 16 <= total && q >= D) {
+    const U128U a = ld128(in.src + (p - D)), b = ld128(in.src + (q - D));
+    const uint64_t x0 = (((uint64_t)(a.b ^ b.b)) << 32) | (a.a ^ b.a);
+    const uint64_t x1 = (((uint64_t)(a.d ^ b.d)) << 32) | (a.c ^ b.c);
+    return x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+  }
+  const uint32_t e = eq8<HAS_DICT>(in, w, p, q, total);
+  return e < 8 ? e : 8 + eq8<HAS_DICT>(in, w, p + 8, q + 8, total);
+}
+
+// v of lane (this - D) within a row of 16 lanes; lanes without such a source get `fill`.
+template <int D>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + D, 0xF, 0xF, false);
+}
+
 template <bool HAS_DICT>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
@@ -145,193 +168,248 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   if (total > kPosMask - 1) return LZ4MI_UNSUPPORTED_HERE;  // table positions are 24-bit
   const uint32_t gtag = gen << kPosBits;
   uint32_t anchor = D, op = 0;
-  Win w;
-  w.lds = lds;
-  w.src = in.src;
-  w.n = n;
-  w.lo = w.hi = 0;
-  w.pending = false;
-  w.pend_pos = 0;
   PH_DECL
 
   if (n >= 4) {  // :74-78
-    while (anchor + 4 <= total) {
-      bool matched = false;
-      uint32_t o_last = 0;
-      win_prepare(w, anchor - D, lane);
-      for (uint32_t chunk = 0;; chunk++) {
-        uint32_t o, nl;
-        if (chunk == 0) {
-          o = offA; nl = 8;
-        } else if (chunk == 1) {
-          o = offB; nl = kWave;
-        } else {
-          o = o_last; nl = kWave;
-          for (uint32_t t = 0; t < kWave; t++)
-            if (t <= lane) o = sched_next(o, sh);
-        }
-        uint32_t ik = anchor + o;
-        bool valid = lane < nl && ik + 4 <= total;
-        const uint64_t vmask = ballot(valid);  // valid lanes form a prefix
-        uint32_t nvalid = (uint32_t)__builtin_popcountll(vmask);
-        if (nvalid == 0) break;
-        PH(0); PH_CNT(8);
-        uint32_t seq = 0, h = 0;
-        int32_t ref = -1;
-        if (valid) {
-          seq = rd32<HAS_DICT>(in, w, ik);
-          h = hash16(seq);
-          uint32_t e = tbl_load(T + h);
-          if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
-          else if (HAS_DICT) ref = (int32_t)dictT[h] - 1;
-        }
-#ifdef LZ4MI_PROFILE
-        { uint64_t w_ = ballot(ref >= 0); asm volatile("" ::"s"(w_)); }
-#endif
-        PH(1);
-        // Earlier probes of this chunk that land in the same bucket act as the table entry
-        // (:99-100 in program order): the nearest earlier lane with an equal hash wins.
-#ifdef LZ4MI_ABL_NOCOLL
-        if (false) {
-#else
-        if (nvalid <= 12) {
-#endif
-          for (uint32_t j = 0; j + 1 < nvalid; j++) {
-            uint32_t hj = rdlane(h, j);
-            if (ballot(valid && lane > j && h == hj)) {
-              uint32_t ij = rdlane(ik, j);
-              if (valid && lane > j && h == hj) ref = (int32_t)ij;
-            }
-          }
-#ifdef LZ4MI_ABL_NOCOLL
-        } else if (false) {
-#else
-        } else {
-#endif
-          uint64_t peers = vmask & ((1ull << lane) - 1ull);
-          for (uint32_t bit = 0; bit < 16; bit++) {
-            bool set = (h >> bit) & 1u;
-            uint64_t m = ballot(set);
-            peers &= set ? m : ~m;
-          }
-          if (!valid) peers = 0;
-          uint32_t j = peers ? 63u - (uint32_t)__builtin_clzll(peers) : lane;
-          uint32_t ij = (uint32_t)__shfl((int)ik, (int)j);
-          if (peers) ref = (int32_t)ij;
-        }
-        PH(2);
-        bool hit = false;
-        if (valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu)  // :102-103
-          hit = rd32<HAS_DICT>(in, w, (uint32_t)ref) == seq;
-        uint64_t hm = ballot(hit);
-        win_service(w, anchor - D, lane);
-        uint32_t K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
-        if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe up to the hit
-        PH(3);
-        if (hm) {
-          PH_CNT(9);
-          const uint32_t i = rdlane(ik, K);
-          const uint32_t r0 = rdlane((uint32_t)ref, K);
-          const uint32_t dist = i - r0;
-          // One round trip for both directions: lanes 0-31 compare one byte each going
-          // backwards (:107-113), lanes 32-63 compare 8 bytes each going forwards (:117-121).
-          const uint32_t maxb = i - anchor < r0 ? i - anchor : r0;
-          bool stop;
-          uint32_t eq = 0;
-          if (lane < 32) {
-            stop = !(lane < maxb && rd8<HAS_DICT>(in, w, i - 1 - lane) == rd8<HAS_DICT>(in, w, r0 - 1 - lane));
-          } else {
-            uint32_t pp = i + 4 + 8 * (lane - 32);
-            eq = eq8<HAS_DICT>(in, w, pp, pp - dist, total);
-            stop = eq < 8;
-          }
-          const uint64_t sm = ballot(stop);
-          uint32_t b = (uint32_t)sm ? (uint32_t)__builtin_ctz((uint32_t)sm) : 32u;
-          while (b >= 32 && b < maxb) {  // long backward run: 64 bytes per step
-            uint32_t t = b + lane;
-            bool same = t < maxb && rd8<HAS_DICT>(in, w, i - 1 - t) == rd8<HAS_DICT>(in, w, r0 - 1 - t);
-            uint64_t m = ballot(!same);
-            if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
-            b += kWave;
-          }
-          const uint32_t ms = i - b;
-          PH(4);
-          uint32_t fwd;
-          if ((uint32_t)(sm >> 32)) {
-            uint32_t L = (uint32_t)__builtin_ctz((uint32_t)(sm >> 32));
-            fwd = 8 * L + rdlane(eq, 32 + L);
-          } else {  // longer than 256 bytes: 512 bytes per step
-            fwd = 256;
-            for (;;) {
-              uint32_t pp = i + 4 + fwd + 8 * lane;
-              uint32_t e8 = eq8<HAS_DICT>(in, w, pp, pp - dist, total);
-              uint64_t m = ballot(e8 < 8);
-              if (m) {
-                uint32_t L = (uint32_t)__builtin_ctzll(m);
-                fwd += 8 * L + rdlane(e8, L);
-                break;
-              }
-              fwd += 8 * kWave;
-            }
-          }
-          const uint32_t ml = b + 4 + fwd;
-          const uint32_t lit = ms - anchor;
-          PH(5);
-          // _writeSequence :172-200
-          const uint32_t m4 = ml - 4;
-#ifndef LZ4MI_ABL_NOEMIT
-          if (lane == 0) out[op] = (uint8_t)(((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u));
-          op++;
-          if (lit >= 15) op = emit_len(out, op, lit - 15, lane);
-          if (lit) {
-            if (lit <= 256 && win_has(w, anchor - D, lit)) {
-              for (uint32_t k = lane; k < lit; k += kWave) out[op + k] = (uint8_t)win_u8(w, anchor - D + k);
-            } else {
-              wave_copy(out + op, in.src + (anchor - D), lit, lane);
-            }
-          }
-          op += lit;
-          if (lane == 0) {
-            out[op] = (uint8_t)dist;
-            out[op + 1] = (uint8_t)(dist >> 8);
-          }
-          op += 2;
-          if (m4 >= 15) op = emit_len(out, op, m4 - 15, lane);
-#endif
-          anchor = ms + ml;  // :132-133
-          matched = true;
-          PH(6);
-#ifndef LZ4MI_ABL_NOREHASH
-          if (anchor + 4 <= total) {  // :135-145 interior re-hash, last `dist` positions only
-            uint32_t hi = anchor - 4;
-            uint32_t lo = ms + 1;
-            if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
-            for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
-              const uint32_t j = j0 + lane;
-              const bool live = j <= hi;
-              uint32_t hj = live ? hash16(rd32<HAS_DICT>(in, w, j)) : 0u;
-              if (live) tbl_max(T + hj, gtag | (j + 1));
-            }
-          }
-#endif
-          PH(7);
-          break;
-        }
-        if (nvalid < nl) break;  // schedule ran past total-4 without a hit
-        o_last = rdlane(o, nl - 1);
+    Win w = {lds, in.src, n, 0, 0};
+    while (anchor + 4 <= total) {  // one iteration per sequence
+      const uint32_t s = anchor - D;
+      {
+        const uint32_t need = s + kLead < n ? s + kLead : n;
+        if (s < w.lo || w.hi < need) win_fill(w, s, need, lane);
       }
-      if (!matched) break;
+      // the next segment is requested together with the table gather and lands after the same wait
+      const bool pend = w.hi < n && w.hi < s + kLead + kSeg;
+      u32x4 pv = {0, 0, 0, 0};
+      if (pend) pv = seg_load(w, w.hi, lane);
+      PH(0); PH_CNT(8);
+
+      // ---- first 8 probes of the run (:95-103): bytes from the ring
+      uint32_t ik = anchor + offA;
+      bool valid = lane < 8 && ik + 4 <= total;
+      uint32_t seq = w32(w, ik - D);
+      uint32_t h = hash16(seq);
+      int32_t ref = -1;
+      {
+        // Every lane loads (idle lanes re-read bucket 0): a gather without a branch around it
+        // gives one unconditional wait, which also covers the segment requested above.
+        const uint32_t hx = valid ? h : 0u;
+        const uint32_t e = tbl_load(T + hx);
+        const uint32_t ed = HAS_DICT ? dictT[hx] : 0u;
+        if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
+        else if (HAS_DICT) ref = (int32_t)ed - 1;
+      }
+      uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));  // >= 1, valid lanes form a prefix
+#ifdef LZ4MI_PROFILE
+      { uint64_t w_ = ballot(ref >= 0); asm volatile("" ::"s"(w_)); }
+#endif
+      PH(1);
+      {
+        // Earlier probes of the run that land in the same bucket act as the table entry (:99-100
+        // in program order).  Equal hashes among 8 probes are rare: detect with row shifts, resolve
+        // out of line.
+        uint32_t mn = h ^ row_shr<1>(h, ~0u);
+        mn = min(mn, h ^ row_shr<2>(h, ~0u));
+        mn = min(mn, h ^ row_shr<3>(h, ~0u));
+        mn = min(mn, h ^ row_shr<4>(h, ~0u));
+        mn = min(mn, h ^ row_shr<5>(h, ~0u));
+        mn = min(mn, h ^ row_shr<6>(h, ~0u));
+        mn = min(mn, h ^ row_shr<7>(h, ~0u));
+        if (ballot(valid && mn == 0)) {
+          for (uint32_t j = 0; j + 1 < nvalid; j++) {  // nearest earlier lane with an equal hash wins
+            const uint32_t hj = rdlane(h, j), ij = rdlane(ik, j);
+            if (valid && lane > j && h == hj) ref = (int32_t)ij;
+          }
+        }
+      }
+      PH(2);
+      uint64_t hm;
+      {
+        const bool cand = valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu;  // :102
+        const bool rnear = cand && (uint32_t)ref >= D + w.lo;                   // ref + 4 <= ik + 4 <= w.hi
+        uint32_t rb = w32(w, (uint32_t)ref - D);
+        if (ballot(cand && !rnear)) {
+          if (cand && !rnear) rb = in_ld32<HAS_DICT>(in, (uint32_t)ref);
+        }
+        hm = ballot(cand && rb == seq);  // :103
+      }
+      if (pend) seg_store(w, w.hi, pv, lane);
+      uint32_t K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
+      PH(3);
+
+      // ---- the rest of the run, 64 probes at a time
+      if (!hm && nvalid == 8) {
+        if (valid) tbl_max(T + h, gtag | (ik + 1));  // :100, all 8 missed
+        valid = false;
+        uint32_t o_last = 0;
+        for (uint32_t chunk = 1;; chunk++) {
+          uint32_t o = offB;
+          if (chunk > 1) {
+            o = o_last;
+            for (uint32_t t = 0; t < kWave; t++)
+              if (t <= lane) o = sched_next(o, sh);
+          }
+          ik = anchor + o;
+          valid = ik + 4 <= total;  // a prefix of the lanes
+          nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
+          if (nvalid == 0) break;
+          PH_CNT(8);
+          seq = 0; h = 0; ref = -1;
+          if (valid) {
+            seq = rd32<HAS_DICT>(in, w, ik);
+            h = hash16(seq);
+            const uint32_t e = tbl_load(T + h);
+            const uint32_t ed = HAS_DICT ? dictT[h] : 0u;
+            if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
+            else if (HAS_DICT) ref = (int32_t)ed - 1;
+          }
+          {  // same-bucket probes of this chunk, nearest earlier lane: 16 bit-plane votes
+            uint64_t peers = valid ? ((1ull << lane) - 1ull) : 0ull;
+            for (uint32_t bit = 0; bit < 16; bit++) {
+              const bool set = (h >> bit) & 1u;
+              const uint64_t m = ballot(set);
+              peers &= set ? m : ~m;
+            }
+            const uint32_t j = peers ? 63u - (uint32_t)__builtin_clzll(peers) : lane;
+            const uint32_t ij = (uint32_t)__shfl((int)ik, (int)j);
+            if (peers) ref = (int32_t)ij;
+          }
+          bool hit = false;
+          if (valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu) hit = rd32<HAS_DICT>(in, w, (uint32_t)ref) == seq;
+          hm = ballot(hit);
+          K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
+          if (hm) break;  // the probes up to the hit are inserted once the sequence is written
+          if (valid) tbl_max(T + h, gtag | (ik + 1));
+          valid = false;
+          if (nvalid < kWave) break;
+          o_last = rdlane(o, kWave - 1);
+        }
+      }
+      if (!hm) break;  // the schedule ran past total - 4 without a hit
+
+      // ---- match at lane K
+      PH_CNT(9);
+      const uint32_t i = rdlane(ik, K);
+      const uint32_t r0 = rdlane((uint32_t)ref, K);
+      const uint32_t dist = i - r0;
+      const uint32_t maxb = i - anchor < r0 ? i - anchor : r0;
+      // One round trip for both directions: lanes 0-31 compare one byte each going backwards
+      // (:107-113), lanes 32-63 compare 8 bytes each going forwards (:117-121).
+      const bool enear = r0 >= D + w.lo + 32 && (i - D + 272 <= w.hi || w.hi >= n);
+      bool stop;
+      uint32_t eq = 0;
+      if (enear) {
+        const uint32_t pp = lane < 32 ? i - 1 - lane : i + 4 + 8 * (lane - 32);
+        const uint64_t x = w64(w, pp - D) ^ w64(w, pp - dist - D);
+        const uint32_t e8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        const uint32_t avail = pp < total ? total - pp : 0u;  // bytes past the block end never count
+        eq = e8 < avail ? e8 : avail;
+        stop = lane < 32 ? !(lane < maxb && e8 != 0) : eq < 8;
+      } else if (r0 >= D + 32 && i + 272 <= total && i - D + 272 <= w.hi) {
+        // reference outside the ring: its side comes from memory (one unconditional 8-byte load per lane)
+        PH_CNT(11);
+        const uint32_t pp = lane < 32 ? i - 1 - lane : i + 4 + 8 * (lane - 32);
+        const uint64_t x = w64(w, pp - D) ^ ld64(in.src + (pp - dist - D));
+        const uint32_t e8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        eq = e8;
+        stop = lane < 32 ? !(lane < maxb && e8 != 0) : eq < 8;
+      } else {
+        PH_CNT(12);
+        if (lane < 32) {
+          stop = !(lane < maxb && rd8<HAS_DICT>(in, w, i - 1 - lane) == rd8<HAS_DICT>(in, w, r0 - 1 - lane));
+        } else {
+          const uint32_t pp = i + 4 + 8 * (lane - 32);
+          eq = eq8<HAS_DICT>(in, w, pp, pp - dist, total);
+          stop = eq < 8;
+        }
+      }
+      const uint64_t sm = ballot(stop);
+      uint32_t b = (uint32_t)sm ? (uint32_t)__builtin_ctz((uint32_t)sm) : 32u;
+      while (b >= 32 && b < maxb) {  // long backward run: 64 bytes per step
+        const uint32_t t = b + lane;
+        const bool same = t < maxb && rd8<HAS_DICT>(in, w, i - 1 - t) == rd8<HAS_DICT>(in, w, r0 - 1 - t);
+        const uint64_t m = ballot(!same);
+        if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
+        b += kWave;
+      }
+      const uint32_t ms = i - b;
+      PH(4);
+      uint32_t fwd;
+      if ((uint32_t)(sm >> 32)) {
+        const uint32_t L = (uint32_t)__builtin_ctz((uint32_t)(sm >> 32));
+        fwd = 8 * L + rdlane(eq, 32 + L);
+      } else {  // longer than 256 bytes: 1 KiB per step
+        fwd = 256;
+        for (;;) {
+          const uint32_t pp = i + 4 + fwd + 16 * lane;
+          const uint32_t e16 = eq16g<HAS_DICT>(in, w, pp, pp - dist, total);
+          const uint64_t m = ballot(e16 < 16);
+          if (m) {
+            const uint32_t L = (uint32_t)__builtin_ctzll(m);
+            fwd += 16 * L + rdlane(e16, L);
+            break;
+          }
+          fwd += 16 * kWave;
+        }
+      }
+      const uint32_t ml = b + 4 + fwd;
+      const uint32_t lit = ms - anchor;
+      const uint32_t m4 = ml - 4;
+      PH(5);
+
+      // ---- _writeSequence :172-200
+      {
+        const uint32_t e1 = lit >= 15 ? 1u : 0u;                       // one extension byte covers lit <= 269
+        const uint32_t mx = m4 >= 15 ? (m4 - 15) / 255u + 1u : 0u;     // match-length extension bytes
+        const uint32_t slen = 1 + e1 + lit + 2 + mx;
+        if (lit <= 200 && slen <= 2 * kWave) {
+          // the whole sequence is one or two wave-wide byte stores; literals come from the ring
+          const uint32_t h0 = 1 + e1, po = h0 + lit, px = po + 2;
+          const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u);
+          for (uint32_t base = 0; base < slen; base += kWave) {
+            const uint32_t x = base + lane;
+            uint32_t v = w8(w, s + x - h0);
+            if (x >= px) v = x + 1 == slen ? (m4 - 15) % 255u : 255u;
+            if (x == po) v = dist & 0xFFu;
+            if (x == po + 1) v = dist >> 8;
+            if (x == 1 && e1) v = lit - 15;
+            if (x == 0) v = token;
+            if (x < slen) out[op + x] = (uint8_t)v;
+          }
+          op += slen;
+        } else {
+          PH_CNT(13);
+          op = emit_sequence(out, op, in.src + s, lit, dist, ml, lane);
+        }
+      }
+      anchor = ms + ml;  // :132-133
+      if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe of the last chunk up to the hit
+      PH(6);
+
+      // ---- :135-145 interior re-hash, last `dist` positions only
+      if (anchor + 4 <= total) {
+        const uint32_t hi = anchor - 4;
+        uint32_t lo = ms + 1;
+        if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
+        if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
+          for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            const uint32_t hj = hash16(w32(w, j - D));
+            if (j <= hi) tbl_max(T + hj, gtag | (j + 1));
+          }
+        } else {
+          for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            if (j <= hi) tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
+          }
+        }
+      }
+      PH(7);
     }
   }
   // _writeLastLiterals :153-156, :202-214
   const uint32_t last = total - anchor;
-  if (last != 0) {
-    if (lane == 0) out[op] = (uint8_t)((last < 15 ? last : 15u) << 4);
-    op++;
-    if (last >= 15) op = emit_len(out, op, last - 15, lane);
-    wave_copy(out + op, in.src + (anchor - D), last, lane);
-    op += last;
-  }
+  if (last != 0) op = emit_last_literals(out, op, in.src + (anchor - D), last, lane);
   PH(10);
   PH_FLUSH(g_enc_phase, lane);
   out_len = op;
@@ -341,7 +419,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
 template <bool HAS_DICT>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t sh, EncodeScratch sc,
                                                           uint32_t *counter) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + wave);

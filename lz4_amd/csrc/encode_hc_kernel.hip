@@ -27,20 +27,20 @@ struct HcTables {
 };
 
 __device__ __forceinline__ int32_t hc_head_get(const HcTables &t, uint32_t h) {
-  uint32_t e = __hip_atomic_load(t.head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t e = __hip_atomic_load(t.head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if ((e >> kPosBits) == t.gen) return (int32_t)(e & kPosMask) - 1;
   if (t.dict_head) return (int32_t)t.dict_head[h] - 1;
   return -1;
 }
 __device__ __forceinline__ void hc_head_set(const HcTables &t, uint32_t h, uint32_t pos) {
-  __hip_atomic_store(t.head + h, (t.gen << kPosBits) | (pos + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(t.head + h, (t.gen << kPosBits) | (pos + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ int32_t hc_chain_get(const HcTables &t, uint32_t pos) {
   if (pos < t.D) return (int32_t)t.dict_chain[pos] - 1;
-  return (int32_t)__hip_atomic_load(t.chain + (pos - t.D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1;
+  return (int32_t)__hip_atomic_load(t.chain + (pos - t.D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - 1;
 }
 __device__ __forceinline__ void hc_chain_set(const HcTables &t, uint32_t pos, int32_t prev) {
-  __hip_atomic_store(t.chain + (pos - t.D), (uint32_t)(prev + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(t.chain + (pos - t.D), (uint32_t)(prev + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // insert(pos) for pos = lo..hi ascending (:96-103), 64 positions per step.
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(64) void hc_dict_prime_kernel(const uint8_t *dict, 
       const uint64_t earlier = same & ((1ull << lane) - 1ull);
       const uint64_t later = same & ~((2ull << lane) - 1ull);
       uint32_t link = earlier ? base + 63u - (uint32_t)__builtin_clzll(earlier) + 1u
-                              : __hip_atomic_load(dict_head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                              : __hip_atomic_load(dict_head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       dict_chain[p] = link;
-      if (!later) __hip_atomic_store(dict_head + h, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!later) __hip_atomic_store(dict_head + h, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }

@@ -9,7 +9,7 @@ codec = DeviceCodec(0)
 L = N.load()
 NB = 1024
 names = ['0 sched+valid', '1 ld32+table gather', '2 collision loop', '3 ref check+tbl write', '4 backward', '5 forward',
-         '6 emit', '7 rehash', '8 #chunks', '9 #matches', '10 tail literals']
+         '6 emit', '7 rehash', '8 #chunks', '9 #matches', '10 tail literals', '11 #ref from memory', '12 #generic extension', '13 #generic emit']
 for cls in [int(a) for a in sys.argv[1:]] or [5, 3, 1]:
     blocks = [corpus_block(cls + 8 * k) for k in range(64)]
     src = torch.from_numpy(np.concatenate([blocks[k % 64] for k in range(NB)])).cuda()
@@ -22,7 +22,7 @@ for cls in [int(a) for a in sys.argv[1:]] or [5, 3, 1]:
     v = list(buf)
     print(f'class {cls}: {e0.elapsed_time(e1):.3f} ms for {NB} blocks', flush=True)
     for i, nm in enumerate(names):
-        if i in (8, 9):
+        if i in (8, 9, 11, 12, 13):
             print(f'   {nm:28s} {v[i] / NB:10.1f} per block')
         else:
             print(f'   {nm:28s} {v[i] / NB / 100:10.1f} us per block (100 MHz ticks)')
