@@ -28,6 +28,12 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
 }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
 
+// Explicit "all vector-memory operations done" (vmcnt(0) alone).  Placed where the wavefront has
+// just consumed its last outstanding load, it costs nothing and tells the compiler's wait
+// insertion that no load is pending, so it does not add conservative drains of its own in front
+// of later stores and atomics (loads, stores and atomics share one in-order counter on gfx950).
+__device__ __forceinline__ void vm_quiesce() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // Work-queue pop for a persistent wavefront.  Every lane takes part in the atomic (lanes
 // other than 0 add zero) so that no per-lane branch sits in front of the cross-lane read:
 // with `if (lane == 0)` here the compiler may thread lanes 1..63 past the pop of the next

@@ -44,6 +44,9 @@ __device__ __forceinline__ uint32_t sched_next(uint32_t o, uint32_t sh) {
 __device__ __forceinline__ uint32_t tbl_load(const uint32_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void tbl_store(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void tbl_max(uint32_t *p, uint32_t v) {
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

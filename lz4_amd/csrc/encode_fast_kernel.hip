@@ -45,6 +45,7 @@ __device__ unsigned long long g_enc_phase[PH_SLOTS];
 #define LZ4MI_WIN 8192
 #endif
 constexpr uint32_t kWinBytes = LZ4MI_WIN, kWinMask = kWinBytes - 1, kSeg = 1024, kWinPad = 16;
+constexpr uint32_t kClaimSlots = 256;  // LDS dwords per wavefront for the same-bucket vote of the re-hash
 constexpr uint32_t kLead = 640;  // an iteration may read ring bytes up to anchor + kLead
 
 struct __attribute__((packed)) P32 { uint32_t v; };
@@ -158,7 +159,7 @@ template <bool HAS_DICT>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
-                                                     uint32_t lane, uint32_t &out_len) {
+                                                     lds_u32 *claim, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t n = total - D;
@@ -234,6 +235,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         hm = ballot(cand && rb == seq);  // :103
       }
       if (pend) seg_store(w, w.hi, pv, lane);
+      vm_quiesce();
       uint32_t K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
       PH(3);
 
@@ -284,8 +286,10 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           if (nvalid < kWave) break;
           o_last = rdlane(o, kWave - 1);
         }
+        vm_quiesce();
       }
       if (!hm) break;  // the schedule ran past total - 4 without a hit
+      PH(14);
 
       // ---- match at lane K
       PH_CNT(9);
@@ -314,7 +318,6 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         eq = e8;
         stop = lane < 32 ? !(lane < maxb && e8 != 0) : eq < 8;
       } else {
-        PH_CNT(12);
         if (lane < 32) {
           stop = !(lane < maxb && rd8<HAS_DICT>(in, w, i - 1 - lane) == rd8<HAS_DICT>(in, w, r0 - 1 - lane));
         } else {
@@ -352,6 +355,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           fwd += 16 * kWave;
         }
       }
+      vm_quiesce();  // every read of this sequence is done; only writes follow
       const uint32_t ml = b + 4 + fwd;
       const uint32_t lit = ms - anchor;
       const uint32_t m4 = ml - 4;
@@ -378,8 +382,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           }
           op += slen;
         } else {
-          PH_CNT(13);
           op = emit_sequence(out, op, in.src + s, lit, dist, ml, lane);
+          vm_quiesce();  // rare path: leave no load pending at the join
         }
       }
       anchor = ms + ml;  // :132-133
@@ -392,16 +396,32 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         uint32_t lo = ms + 1;
         if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
         if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
+          // Inserts go out as plain stores (a store to a line that is not cached needs no fetch,
+          // an atomic does).  Positions rise with the lane, so of the lanes of one instruction that
+          // share a bucket only the highest may store: each lane max-claims a slot of a small LDS
+          // array with its lane number and looks at the winner's hash.  Same hash: the winner is
+          // the bucket's highest lane.  Different hash (two buckets met in one slot): undecided,
+          // those lanes fall back to the atomic max, which is always right.
           for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
             const uint32_t j = j0 + lane;
             const uint32_t hj = hash16(w32(w, j - D));
-            if (j <= hi) tbl_max(T + hj, gtag | (j + 1));
+            const bool live = j <= hi;
+            lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
+            if (live) (void)__hip_atomic_fetch_max(slot, lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const uint32_t top = live ? *slot : lane + 1;
+            const uint32_t htop = (uint32_t)__shfl((int)hj, (int)(top - 1));
+            if (live) {
+              *slot = 0;
+              if (htop != hj) tbl_max(T + hj, gtag | (j + 1));
+              else if (top == lane + 1) tbl_store(T + hj, gtag | (j + 1));
+            }
           }
         } else {
           for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
             const uint32_t j = j0 + lane;
             if (j <= hi) tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
           }
+          vm_quiesce();  // rare path: leave no load pending at the join
         }
       }
       PH(7);
@@ -420,11 +440,16 @@ template <bool HAS_DICT>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t sh, EncodeScratch sc,
                                                           uint32_t *counter) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
+  __shared__ uint32_t s_claim[4][kClaimSlots];
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + wave);
+#ifdef LZ4MI_PROFILE
+  const unsigned long long life0 = __builtin_amdgcn_s_memrealtime();
+#endif
   uint32_t *T = sc.tables + (size_t)slot * kHashEntries;
   uint32_t gen = uni(sc.slot_gen[slot]);
+  for (uint32_t k = lane; k < kClaimSlots; k += kWave) s_claim[wave][k] = 0;
 
   // probe schedule: offA = off(lane), offB = off(lane + 8)
   uint32_t offA = 0, offB = 0;
@@ -452,7 +477,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;
-    int32_t st = encode_block_fast<HAS_DICT>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, (lds_u8 *)s_win[wave], lane,
+    int32_t st = encode_block_fast<HAS_DICT>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane,
                                              out_len);
     if (lane == 0) {
       a.out_len[b] = out_len;
@@ -460,6 +485,9 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
     }
   }
   if (lane == 0) sc.slot_gen[slot] = gen;
+#ifdef LZ4MI_PROFILE
+  if (lane == 0) atomicMax(&g_enc_phase[13], __builtin_amdgcn_s_memrealtime() - life0);
+#endif
 }
 
 // Dictionary priming (:83-88): bucket <- largest dictionary position + 1.

@@ -7,9 +7,9 @@ from lz4_amd.device import DeviceCodec
 from tools.corpus import corpus_block
 codec = DeviceCodec(0)
 L = N.load()
-NB = 1024
+NB = int(__import__('os').environ.get('NB', '1024'))
 names = ['0 sched+valid', '1 ld32+table gather', '2 collision loop', '3 ref check+tbl write', '4 backward', '5 forward',
-         '6 emit', '7 rehash', '8 #chunks', '9 #matches', '10 tail literals', '11 #ref from memory', '12 #generic extension', '13 #generic emit']
+         '6 emit', '7 rehash', '8 #chunks', '9 #matches', '10 tail literals', '11 #ref from memory', '12 realtime 100MHz ticks', '13 max wave lifetime x NB (100MHz ticks)', '14 later chunks', '15 total cycles']
 for cls in [int(a) for a in sys.argv[1:]] or [5, 3, 1]:
     blocks = [corpus_block(cls + 8 * k) for k in range(64)]
     src = torch.from_numpy(np.concatenate([blocks[k % 64] for k in range(NB)])).cuda()
