@@ -5,16 +5,18 @@
 // (lib/src/internal/byte_writer.dart:93-121) check for check, so the status of
 // a malformed block equals the exception the reference raises.
 //
-// Layout: the token stream is parsed wave-uniformly out of a 512-byte register
-// window of the compressed block (two dwords per lane, fetched with one
-// coalesced load and read back with v_readlane), so the parse chain never
-// waits on memory.  Short literal runs are taken from that same register window
-// (ds_bpermute), and the most recent 8 KiB of output are mirrored in an LDS ring
-// per wavefront, so a short match whose source is recent is served from LDS: a
-// typical sequence then needs no memory round trip at all, only stores.
-// Long runs go memory to memory with 16-byte aligned stores (1 KiB per
-// wave-instruction); matches that overlap their own output replicate the period
-// with a modulo gather.
+// Layout: the token stream is parsed wave-uniformly out of a 1 KiB register window of the
+// compressed block (four dwords per lane, fetched with one coalesced load and read back with
+// v_readlane); a refill of that window is the only point where the parse waits on memory.
+// Short literal runs are taken from the same registers (ds_bpermute), and the most recent
+// 8 KiB of output are mirrored in an LDS ring per wavefront, so a short match whose source is
+// recent is served from LDS: a typical sequence needs no memory round trip at all, only stores.
+// That matters because loads, stores and atomics of a wavefront retire through one in-order
+// counter on gfx950: any load issued behind output stores waits for all of them.  Paths that
+// do load (far matches, long runs, window refills) end with an explicit vmcnt(0) so that the
+// compiler's wait insertion never adds a drain of its own to the load-free paths.
+// Long runs go memory to memory with 16-byte aligned stores (1 KiB per wave-instruction);
+// matches that overlap their own output replicate the period with a modulo gather.
 #include "device_common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -25,45 +27,52 @@ namespace lz4mi {
 __device__ unsigned long long g_dec_phase[PH_SLOTS];
 #endif
 
+// 1 KiB of the compressed block in registers: lane l holds the dwords at v-space offsets
+// base + 4*l + 256*k (k = 0..3), v-space being byte offsets from the 4-byte aligned address
+// at or below src.  A refill is the only point where the parse waits on memory.
 struct InWindow {
   const uint8_t *al;   // 4-byte aligned base (src - mis)
   uint32_t mis;        // src - al, 0..3
   uint32_t vend;       // mis + src_len rounded up to 4
-  uint32_t base;       // window start in v-space (multiple of 4), covers [base, base+512)
-  uint32_t w0, w1;     // per-lane dwords
-  uint32_t nbase;      // prefetched next window
-  uint32_t n0, n1;
+  uint32_t base;       // window start in v-space (multiple of 4), covers [base, base + 1024)
+  uint32_t r0, r1, r2, r3;
 };
-
-__device__ __forceinline__ void win_load(const InWindow &w, uint32_t base, uint32_t lane, uint32_t &r0,
-                                         uint32_t &r1) {
-  uint32_t p0 = base + 4 * lane, p1 = p0 + 256;
-  r0 = p0 < w.vend ? *(const uint32_t *)(w.al + p0) : 0u;
-  r1 = p1 < w.vend ? *(const uint32_t *)(w.al + p1) : 0u;
-}
+constexpr uint32_t kInWin = 1024;
 
 __device__ __forceinline__ void win_seek(InWindow &w, uint32_t vpos, uint32_t lane) {
-  if (vpos - w.nbase < 512u) {  // forward into the prefetched window
-    w.w0 = w.n0;
-    w.w1 = w.n1;
-    w.base = w.nbase;
-  } else {
-    w.base = vpos & ~3u;
-    win_load(w, w.base, lane, w.w0, w.w1);
-  }
-  w.nbase = w.base + 512;
-  win_load(w, w.nbase, lane, w.n0, w.n1);
+  w.base = vpos & ~3u;
+  const uint32_t p = w.base + 4 * lane;
+  w.r0 = p < w.vend ? *(const uint32_t *)(w.al + p) : 0u;
+  w.r1 = p + 256 < w.vend ? *(const uint32_t *)(w.al + p + 256) : 0u;
+  w.r2 = p + 512 < w.vend ? *(const uint32_t *)(w.al + p + 512) : 0u;
+  w.r3 = p + 768 < w.vend ? *(const uint32_t *)(w.al + p + 768) : 0u;
+  vm_quiesce();
+}
+
+// dword d (0..255) of the window, d wave-uniform
+__device__ __forceinline__ uint32_t win_word(const InWindow &w, uint32_t d) {
+  const uint32_t l = d & 63u;
+  const uint32_t a = rdlane(w.r0, l), b = rdlane(w.r1, l), c = rdlane(w.r2, l), e = rdlane(w.r3, l);
+  const uint32_t lo = (d & 64u) ? b : a, hi = (d & 64u) ? e : c;
+  return (d & 128u) ? hi : lo;
 }
 
 // byte at real offset `pos` of the compressed block (caller guarantees pos < src_len)
 __device__ __forceinline__ uint32_t win_byte(InWindow &w, uint32_t pos, uint32_t lane) {
   uint32_t v = pos + w.mis;
-  if (v - w.base >= 512u) win_seek(w, v, lane);
-  uint32_t rel = v - w.base;
-  uint32_t d = rel >> 2;
-  uint32_t a = rdlane(w.w0, d & 63u), b = rdlane(w.w1, d & 63u);
-  uint32_t word = (d & 64u) ? b : a;
-  return (word >> ((rel & 3u) * 8u)) & 0xffu;
+  if (v - w.base >= kInWin) win_seek(w, v, lane);
+  const uint32_t rel = v - w.base;
+  return (win_word(w, rel >> 2) >> ((rel & 3u) * 8u)) & 0xffu;
+}
+
+// little-endian 16 bits at real offset pos (caller guarantees pos + 2 <= src_len)
+__device__ __forceinline__ uint32_t win_u16(InWindow &w, uint32_t pos, uint32_t lane) {
+  uint32_t v = pos + w.mis;
+  if (v - w.base >= kInWin - 1) win_seek(w, v, lane);
+  const uint32_t rel = v - w.base, d = rel >> 2;
+  const uint32_t lo = win_word(w, d);
+  if ((rel & 3u) != 3u) return (lo >> ((rel & 3u) * 8u)) & 0xffffu;
+  return (lo >> 24) | ((win_word(w, d + 1) & 0xffu) << 8);
 }
 
 // Sum of length-extension bytes (lz4_block_decoder.dart:121-130).  Returns false on
@@ -78,6 +87,7 @@ __device__ __forceinline__ bool read_ext(InWindow &w, const uint8_t *__restrict_
     len += b;
     if (b != 255u) return true;
   }
+  bool ok;
   for (;;) {
     uint32_t p = ip + lane;
     uint32_t b = p < in_end ? (uint32_t)src[p] : 0x100u;  // 0x100 marks "past the end"
@@ -92,12 +102,16 @@ __device__ __forceinline__ bool read_ext(InWindow &w, const uint8_t *__restrict_
     len += 255u * f;
     if (bf == 0x100u) {
       ip += f;
-      return false;
+      ok = false;
+    } else {
+      len += bf;
+      ip += f + 1;
+      ok = true;
     }
-    len += bf;
-    ip += f + 1;
-    return true;
+    break;
   }
+  vm_quiesce();
+  return ok;
 }
 
 template <bool HAS_PREFIX>
@@ -113,6 +127,7 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
       wave_copy(dst + op, prefix + prefix_len + s, npre, lane);
       if (ml > npre) wave_copy(dst + op + npre, dst, ml - npre, lane);
     }
+    vm_quiesce();
     return;
   }
   // Overlapping match: byte-serial forward copy semantics (byte_writer.dart:116-118)
@@ -130,19 +145,27 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
     r += step;
     if (r >= dist) r -= dist;
   }
+  vm_quiesce();
 }
 
-constexpr uint32_t kRing = 8192;   // bytes of recent output mirrored in LDS per wavefront
+#ifndef LZ4MI_RING
+#define LZ4MI_RING 8192
+#endif
+constexpr uint32_t kRing = LZ4MI_RING;   // bytes of recent output mirrored in LDS per wavefront
 constexpr uint32_t kShort = 256;   // copies up to this length go through the ring path
 
-// Byte at compressed offset pos + lane for lanes < n, straight from the register window.
-// Caller guarantees [pos, pos + n) lies inside the resident 512-byte window.
+// Byte at compressed offset pos + lane, straight from the register window.  Caller guarantees
+// that [pos, pos + 64) clipped to the literal run lies inside the window.
 __device__ __forceinline__ uint32_t win_lane_byte(const InWindow &w, uint32_t pos, uint32_t lane) {
-  uint32_t rel = pos + lane + w.mis - w.base;
-  uint32_t d = rel >> 2;
-  uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)w.w0);
-  uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)w.w1);
-  uint32_t word = (d & 64u) ? b : a;
+  const uint32_t rel = pos + lane + w.mis - w.base;
+  const uint32_t d = rel >> 2;
+  const int sel = (int)((d & 63u) << 2);
+  const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r0);
+  const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r1);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r2);
+  const uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r3);
+  const uint32_t lo = (d & 64u) ? b : a, hi = (d & 64u) ? e : c;
+  const uint32_t word = (d & 128u) ? hi : lo;
   return (word >> ((rel & 3u) * 8u)) & 0xffu;
 }
 
@@ -160,9 +183,8 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   w.mis = (uint32_t)((uintptr_t)src & 3u);
   w.al = src - w.mis;
   w.vend = (w.mis + src_len + 3u) & ~3u;
-  w.base = 0xfffffc00u;  // nothing loaded yet
-  w.nbase = 0xfffff000u;
-  w.w0 = w.w1 = w.n0 = w.n1 = 0;
+  w.base = 0xfffff000u;  // nothing loaded yet
+  w.r0 = w.r1 = w.r2 = w.r3 = 0;
 
   uint32_t ip = 0, op = 0;  // op counts bytes written by this block
   uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
@@ -194,19 +216,21 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       const uint32_t lit = (uint32_t)lit64;
       PH(0);
       if (lit <= kShort) {
-        const bool in_regs = ip + lit + w.mis <= w.base + 512u;  // ip itself is resident (token just read)
+        // short run: bytes come out of the register window (re-centred on ip if the run crosses its end)
+        if (ip + lit + w.mis > w.base + kInWin) win_seek(w, ip + w.mis, lane);
         for (uint32_t k0 = 0; k0 < lit; k0 += kWave) {
-          uint32_t k = k0 + lane;
-          uint32_t v = in_regs ? win_lane_byte(w, ip + k0, lane) : (k < lit ? (uint32_t)src[ip + k] : 0u);
+          const uint32_t k = k0 + lane;
+          const uint32_t v = win_lane_byte(w, ip + k0, lane);
           if (k < lit) {
             out[op + k] = (uint8_t)v;
             ring[(op + k) & (kRing - 1)] = (uint8_t)v;
           }
         }
         if (op + lit > rlo + kRing) rlo = op + lit - kRing;
-        PH(1); PH_CNT(8); if (!in_regs) PH_CNT(12);
+        PH(1); PH_CNT(8);
       } else {
         wave_copy(out + op, src + ip, lit, lane);
+        vm_quiesce();
         rlo = op + lit;  // ring holds nothing older than this
         PH(2); PH_CNT(9);
       }
@@ -222,8 +246,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       if (ip >= in_end) break;  // :102-104
     }
     if (in_end - ip < 2) { st = LZ4MI_FORMAT_EOF; break; }  // :50-52 / :106-108
-    uint32_t dist = win_byte(w, ip, lane);
-    dist |= win_byte(w, ip + 1, lane) << 8;
+    const uint32_t dist = win_u16(w, ip, lane);
     ip += 2;
     uint64_t ml64 = (token & 15u) + 4u;
     if ((token & 15u) == 15u) {
@@ -234,7 +257,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     if (dist == 0 || (uint64_t)dist > (uint64_t)op + back_limit) { st = LZ4MI_CORRUPT_DISTANCE; break; }
     if (!STRICT && ml64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; }
     const uint32_t ml = (uint32_t)ml64;
-    PH(0);
+    PH(6);
     if (ml <= kShort) {
       // byte-serial copy semantics (byte_writer.dart:116-118): source byte of output k is
       // k mod dist bytes into the period that ends at op
@@ -246,19 +269,31 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         r = dist >= kWave ? lane : lane % dist;
         step = dist > kWave ? kWave : kWave % dist;
       }
-      for (uint32_t k = lane; k < ml; k += kWave) {
-        int32_t p = s + (int32_t)r;
-        uint32_t v;
-        if (p >= ring_from) {
-          v = ring[(uint32_t)p & (kRing - 1)];
-        } else {
-          int64_t ap = (int64_t)op_start + p;
-          v = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+      if (s >= ring_from) {
+        // the whole source is in the LDS ring: no memory read, nothing to wait for
+        for (uint32_t k = lane; k < ml; k += kWave) {
+          const uint32_t v = ring[(uint32_t)(s + (int32_t)r) & (kRing - 1)];
+          out[op + k] = (uint8_t)v;
+          ring[(op + k) & (kRing - 1)] = (uint8_t)v;
+          r += step;
+          if (overlap && r >= dist) r -= dist;
         }
-        out[op + k] = (uint8_t)v;
-        ring[(op + k) & (kRing - 1)] = (uint8_t)v;
-        r += step;
-        if (overlap && r >= dist) r -= dist;
+      } else {
+        for (uint32_t k = lane; k < ml; k += kWave) {
+          int32_t p = s + (int32_t)r;
+          uint32_t v;
+          if (p >= ring_from) {
+            v = ring[(uint32_t)p & (kRing - 1)];
+          } else {
+            int64_t ap = (int64_t)op_start + p;
+            v = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+          }
+          out[op + k] = (uint8_t)v;
+          ring[(op + k) & (kRing - 1)] = (uint8_t)v;
+          r += step;
+          if (overlap && r >= dist) r -= dist;
+        }
+        vm_quiesce();
       }
       rlo = (uint32_t)ring_from;
       if (s >= ring_from) { PH(3); PH_CNT(10); } else { PH(4); PH_CNT(11); }

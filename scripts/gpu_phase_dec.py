@@ -7,9 +7,9 @@ from lz4_amd.device import DeviceCodec
 from tools.corpus import corpus_block
 codec = DeviceCodec(0)
 L = N.load()
-NB = 1024
+NB = int(__import__('os').environ.get('NB', '1024'))
 names = ['0 parse', '1 short literal', '2 long literal', '3 short match ring', '4 short match global', '5 long match',
-         '6', '7', '8 #short lit', '9 #long lit', '10 #ring match', '11 #global match', '12 #short lit not in regs', '13 #long match']
+         '6 offset+length parse', '7', '8 #short lit', '9 #long lit', '10 #ring match', '11 #global match', '12 realtime ticks (100 MHz)', '13 #long match', '14', '15 total cycles']
 for arg in sys.argv[1:] or ['5']:
     idx = [int(x) for x in arg.split(',')]
     blocks = [corpus_block(i) for i in idx]
@@ -26,5 +26,7 @@ for arg in sys.argv[1:] or ['5']:
     for i, nm in enumerate(names):
         if i >= 8:
             print(f'   {nm:28s} {v[i] / NB:10.1f} per block')
+        elif i == 15:
+            print(f'   {nm:28s} {v[i] / NB / 1000:10.1f} kticks per block')
         elif v[i]:
             print(f'   {nm:28s} {v[i] / NB / 1000:10.1f} kticks per block')
