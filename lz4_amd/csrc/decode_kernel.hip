@@ -29,7 +29,9 @@ __device__ unsigned long long g_dec_phase[PH_SLOTS];
 
 // 1 KiB of the compressed block in registers: lane l holds the dwords at v-space offsets
 // base + 4*l + 256*k (k = 0..3), v-space being byte offsets from the 4-byte aligned address
-// at or below src.  A refill is the only point where the parse waits on memory.
+// at or below src.  A refill is the only point where the parse waits on memory.  (Requesting
+// the next window ahead of time was measured slower: with loads in flight the compiler guards
+// later register writes with full drains of the output stores.)
 struct InWindow {
   const uint8_t *al;   // 4-byte aligned base (src - mis)
   uint32_t mis;        // src - al, 0..3
@@ -38,6 +40,9 @@ struct InWindow {
   uint32_t r0, r1, r2, r3;
 };
 constexpr uint32_t kInWin = 1024;
+
+// true when the 64 bytes at v-space offset v are inside the window
+__device__ __forceinline__ bool win_covers(const InWindow &w, uint32_t v) { return v - w.base <= kInWin - 64; }
 
 __device__ __forceinline__ void win_seek(InWindow &w, uint32_t vpos, uint32_t lane) {
   w.base = vpos & ~3u;
@@ -49,69 +54,66 @@ __device__ __forceinline__ void win_seek(InWindow &w, uint32_t vpos, uint32_t la
   vm_quiesce();
 }
 
-// dword d (0..255) of the window, d wave-uniform
-__device__ __forceinline__ uint32_t win_word(const InWindow &w, uint32_t d) {
-  const uint32_t l = d & 63u;
-  const uint32_t a = rdlane(w.r0, l), b = rdlane(w.r1, l), c = rdlane(w.r2, l), e = rdlane(w.r3, l);
+// Byte at compressed offset pos + lane, straight from the register window.  Caller guarantees
+// that the bytes it goes on to use lie inside the window.
+__device__ __forceinline__ uint32_t win_lane_byte(const InWindow &w, uint32_t pos, uint32_t lane) {
+  const uint32_t rel = pos + lane + w.mis - w.base;
+  const uint32_t d = rel >> 2;
+  const int sel = (int)((d & 63u) << 2);
+  const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r0);
+  const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r1);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r2);
+  const uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r3);
   const uint32_t lo = (d & 64u) ? b : a, hi = (d & 64u) ? e : c;
-  return (d & 128u) ? hi : lo;
+  const uint32_t word = (d & 128u) ? hi : lo;
+  return (word >> ((rel & 3u) * 8u)) & 0xffu;
+}
+
+// The parse reads single bytes (token, length extensions, offset).  One cross-lane gather puts
+// the 64 compressed bytes that follow a position into one register, a byte per lane; after that
+// every byte of the sequence header costs one v_readlane, and a literal run that fits is stored
+// straight from that register.
+struct Stream {
+  uint32_t sp;  // compressed offset of lane 0
+  uint32_t S;   // lane l: byte at sp + l (meaningless at or past the end of the block)
+};
+
+__device__ __forceinline__ void stream_load(InWindow &w, Stream &s, uint32_t pos, uint32_t lane) {
+  const uint32_t v = pos + w.mis;
+  if (!win_covers(w, v)) win_seek(w, v, lane);
+  s.sp = pos;
+  s.S = win_lane_byte(w, pos, lane);
 }
 
 // byte at real offset `pos` of the compressed block (caller guarantees pos < src_len)
-__device__ __forceinline__ uint32_t win_byte(InWindow &w, uint32_t pos, uint32_t lane) {
-  uint32_t v = pos + w.mis;
-  if (v - w.base >= kInWin) win_seek(w, v, lane);
-  const uint32_t rel = v - w.base;
-  return (win_word(w, rel >> 2) >> ((rel & 3u) * 8u)) & 0xffu;
+__device__ __forceinline__ uint32_t sbyte(InWindow &w, Stream &s, uint32_t pos, uint32_t lane) {
+  if (pos - s.sp >= kWave) stream_load(w, s, pos, lane);
+  return rdlane(s.S, pos - s.sp);
 }
 
-// little-endian 16 bits at real offset pos (caller guarantees pos + 2 <= src_len)
-__device__ __forceinline__ uint32_t win_u16(InWindow &w, uint32_t pos, uint32_t lane) {
-  uint32_t v = pos + w.mis;
-  if (v - w.base >= kInWin - 1) win_seek(w, v, lane);
-  const uint32_t rel = v - w.base, d = rel >> 2;
-  const uint32_t lo = win_word(w, d);
-  if ((rel & 3u) != 3u) return (lo >> ((rel & 3u) * 8u)) & 0xffffu;
-  return (lo >> 24) | ((win_word(w, d + 1) & 0xffu) << 8);
-}
-
-// Sum of length-extension bytes (lz4_block_decoder.dart:121-130).  Returns false on
-// running off the end of the input ('Unexpected end of input', byte_reader.dart:102-106).
-__device__ __forceinline__ bool read_ext(InWindow &w, const uint8_t *__restrict__ src, uint32_t &ip,
-                                         uint32_t in_end, uint64_t &len, uint32_t lane) {
-  // a few bytes through the register window, then 64 bytes per step with a ballot
-  for (int k = 0; k < 3; k++) {
-    if (ip >= in_end) return false;
-    uint32_t b = win_byte(w, ip, lane);
-    ip++;
-    len += b;
-    if (b != 255u) return true;
-  }
-  bool ok;
+// Sum of length-extension bytes (lz4_block_decoder.dart:121-130): every byte is added, a byte
+// other than 255 ends the run.  Returns false on running off the end of the input ('Unexpected
+// end of input', byte_reader.dart:102-106).  One vote finds the end of the run among the
+// streamed bytes.
+__device__ __forceinline__ bool read_ext(InWindow &w, Stream &s, uint32_t &ip, uint32_t in_end, uint64_t &len,
+                                         uint32_t lane) {
   for (;;) {
-    uint32_t p = ip + lane;
-    uint32_t b = p < in_end ? (uint32_t)src[p] : 0x100u;  // 0x100 marks "past the end"
-    uint64_t stop = ballot(b != 255u);
-    if (stop == 0) {
-      len += 255u * 64u;
-      ip += 64;
+    if (ip >= in_end) return false;
+    if (ip - s.sp >= kWave) stream_load(w, s, ip, lane);
+    const uint32_t rel = ip - s.sp;
+    const uint64_t m = ballot(lane >= rel && (s.sp + lane >= in_end || s.S != 255u));
+    if (m == 0) {
+      len += 255u * (kWave - rel);
+      ip += kWave - rel;
       continue;
     }
-    uint32_t f = (uint32_t)__builtin_ctzll(stop);
-    uint32_t bf = rdlane(b, f);
-    len += 255u * f;
-    if (bf == 0x100u) {
-      ip += f;
-      ok = false;
-    } else {
-      len += bf;
-      ip += f + 1;
-      ok = true;
-    }
-    break;
+    const uint32_t f = (uint32_t)__builtin_ctzll(m);
+    len += 255u * (f - rel);
+    if (s.sp + f >= in_end) return false;
+    len += rdlane(s.S, f);
+    ip = s.sp + f + 1;
+    return true;
   }
-  vm_quiesce();
-  return ok;
 }
 
 template <bool HAS_PREFIX>
@@ -154,21 +156,6 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
 constexpr uint32_t kRing = LZ4MI_RING;   // bytes of recent output mirrored in LDS per wavefront
 constexpr uint32_t kShort = 256;   // copies up to this length go through the ring path
 
-// Byte at compressed offset pos + lane, straight from the register window.  Caller guarantees
-// that [pos, pos + 64) clipped to the literal run lies inside the window.
-__device__ __forceinline__ uint32_t win_lane_byte(const InWindow &w, uint32_t pos, uint32_t lane) {
-  const uint32_t rel = pos + lane + w.mis - w.base;
-  const uint32_t d = rel >> 2;
-  const int sel = (int)((d & 63u) << 2);
-  const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r0);
-  const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r1);
-  const uint32_t c = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r2);
-  const uint32_t e = (uint32_t)__builtin_amdgcn_ds_bpermute(sel, (int)w.r3);
-  const uint32_t lo = (d & 64u) ? b : a, hi = (d & 64u) ? e : c;
-  const uint32_t word = (d & 128u) ? hi : lo;
-  return (word >> ((rel & 3u) * 8u)) & 0xffu;
-}
-
 // Decodes one block with the whole wave into dst[op_start ...).  `cap` is
 // decompressedSize (STRICT) or the ByteWriter maxLength minus the pre-filled prefix
 // (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
@@ -185,6 +172,9 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   w.vend = (w.mis + src_len + 3u) & ~3u;
   w.base = 0xfffff000u;  // nothing loaded yet
   w.r0 = w.r1 = w.r2 = w.r3 = 0;
+  Stream sm;
+  sm.sp = 0xffffff00u;
+  sm.S = 0;
 
   uint32_t ip = 0, op = 0;  // op counts bytes written by this block
   uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
@@ -203,11 +193,11 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     } else {
       if (ip >= in_end) break;  // :86-88
     }
-    uint32_t token = win_byte(w, ip, lane);
+    uint32_t token = sbyte(w, sm, ip, lane);
     ip++;
     uint64_t lit64 = token >> 4;
     if (lit64 == 15) {
-      if (!read_ext(w, src, ip, in_end, lit64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+      if (!read_ext(w, sm, ip, in_end, lit64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
     }
     if (STRICT && lit64 > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_LITERAL; break; }  // :33-35
     if (lit64 != 0) {
@@ -215,19 +205,33 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       if (!STRICT && lit64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; } // writer maxLength
       const uint32_t lit = (uint32_t)lit64;
       PH(0);
-      if (lit <= kShort) {
-        // short run: bytes come out of the register window (re-centred on ip if the run crosses its end)
-        if (ip + lit + w.mis > w.base + kInWin) win_seek(w, ip + w.mis, lane);
-        for (uint32_t k0 = 0; k0 < lit; k0 += kWave) {
+      if (ip - sm.sp + lit <= kWave) {
+        // the whole run is in the stream register: lanes [rel, rel + lit) store their byte
+        const uint32_t rel = ip - sm.sp;
+        const uint32_t k = lane - rel;
+        if (k < lit) {
+          out[op + k] = (uint8_t)sm.S;
+          ring[(op + k) & (kRing - 1)] = (uint8_t)sm.S;
+        }
+        if (op + lit > rlo + kRing) rlo = op + lit - kRing;
+        PH(1); PH_CNT(8);
+      } else if (lit <= kShort) {
+        // short run: 64 bytes per step out of the register window; the last gather also holds the
+        // bytes that follow the run and becomes the stream register
+        uint32_t v = 0, k0 = 0;
+        for (; k0 < lit; k0 += kWave) {
+          if (!win_covers(w, ip + k0 + w.mis)) win_seek(w, ip + k0 + w.mis, lane);
           const uint32_t k = k0 + lane;
-          const uint32_t v = win_lane_byte(w, ip + k0, lane);
+          v = win_lane_byte(w, ip + k0, lane);
           if (k < lit) {
             out[op + k] = (uint8_t)v;
             ring[(op + k) & (kRing - 1)] = (uint8_t)v;
           }
         }
+        sm.sp = ip + k0 - kWave;
+        sm.S = v;
         if (op + lit > rlo + kRing) rlo = op + lit - kRing;
-        PH(1); PH_CNT(8);
+        PH(1); PH_CNT(14);
       } else {
         wave_copy(out + op, src + ip, lit, lane);
         vm_quiesce();
@@ -246,11 +250,11 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       if (ip >= in_end) break;  // :102-104
     }
     if (in_end - ip < 2) { st = LZ4MI_FORMAT_EOF; break; }  // :50-52 / :106-108
-    const uint32_t dist = win_u16(w, ip, lane);
+    const uint32_t dist = sbyte(w, sm, ip, lane) | (sbyte(w, sm, ip + 1, lane) << 8);
     ip += 2;
     uint64_t ml64 = (token & 15u) + 4u;
     if ((token & 15u) == 15u) {
-      if (!read_ext(w, src, ip, in_end, ml64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
+      if (!read_ext(w, sm, ip, in_end, ml64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
     }
     if (STRICT && ml64 > (uint64_t)(cap - op)) { st = LZ4MI_CORRUPT_MATCH; break; }  // :61-63
     // copyMatch: distance first (byte_writer.dart:97-99), then capacity (:104)
