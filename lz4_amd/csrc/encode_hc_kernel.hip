@@ -1,13 +1,13 @@
 // LZ4HC block encoder for gfx950, byte-identical to lz4HcBlockCompressToWriter
 // (lib/src/hc/lz4_hc_block_encoder.dart:49-197): hash-chain search, depth-bounded, greedy.
 //
-// One wavefront per block replays the reference's loop position by position with the real
-// head table (65536 x u32 per wavefront slot, generation-tagged like the fast encoder's) and
-// the real chain array (u32 per position) in HBM/L2, so every quirk of the reference's chain
-// (positions that are never inserted, re-inserted positions that turn the chain into a cycle,
-// far candidates that still consume search depth, :125-129) is reproduced by construction.
-// The lanes are used for what is parallel inside one step: measuring a candidate's match
-// length (512 bytes per step), the backward extension, sequence emission, and the interior
+// One wavefront per block works on the real head table (65536 x u32 per wavefront slot,
+// generation-tagged like the fast encoder's) and the real chain array (u32 per position) in
+// HBM/L2, so every quirk of the reference's chain (positions that are never inserted,
+// re-inserted positions that turn the chain into a cycle, far candidates that still consume
+// search depth, :125-129) is reproduced by construction.  Positions without a match are taken
+// 64 at a time (see encode_block_hc); the lanes also share the work inside one step: long match
+// lengths (512 bytes per step), the backward extension, sequence emission, and the interior
 // inserts after a match (:180-185), which go 64 positions per step with the in-step order
 // resolved in registers (a position links to the nearest earlier lane of its bucket, the last
 // lane of a bucket becomes its head).
@@ -97,9 +97,38 @@ __device__ __forceinline__ uint32_t hc_match_len(const EncIn &in, uint32_t p, ui
   }
 }
 
+// Equal bytes (>= 4, the caller has compared the first four) of p.. and c.. (c < p), measured by
+// one lane up to kLaneCmp bytes; `more` says the run was still going at that point.
+constexpr uint32_t kLaneCmp = 64;
+template <bool HAS_DICT>
+__device__ __forceinline__ uint32_t hc_lane_len(const EncIn &in, uint32_t p, uint32_t c, uint32_t total, bool &more) {
+  uint32_t len = 4;
+  more = false;
+  for (;;) {
+    if (p + len + 4 <= total) {
+      const uint32_t x = in_ld32<HAS_DICT>(in, p + len) ^ in_ld32<HAS_DICT>(in, c + len);
+      if (x) return len + ((uint32_t)__builtin_ctz(x) >> 3);
+      len += 4;
+      if (len >= kLaneCmp) { more = p + len < total; return len; }
+    } else {
+      while (p + len < total && in_byte<HAS_DICT>(in, p + len) == in_byte<HAS_DICT>(in, c + len)) len++;
+      return len;
+    }
+  }
+}
+
+// The reference visits positions one by one (:116-190), but as long as no match is taken the
+// work at consecutive positions is independent: position p links to the latest earlier position
+// of its bucket and walks that chain.  A wavefront therefore takes 64 consecutive positions at a
+// time, one per lane: links inside the window are resolved in registers (nearest earlier lane of
+// the same bucket, kept in a 64-entry LDS array for the walks), every lane walks its chain in
+// lockstep, and the first lane whose walk found a match is the position where the reference
+// takes its next match.  Only the lanes up to that one are then committed to the head table and
+// chain; the later lanes' work is discarded, so the tables never hold an insert the reference
+// would not have made at that point.
 template <bool HAS_DICT>
 __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out, uint32_t cap, uint32_t max_depth,
-                                                   HcTables t, uint32_t lane, uint32_t &out_len) {
+                                                   HcTables t, lds_u32 *wchain, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t n = total - D;
@@ -111,50 +140,102 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
 
   if (n >= 4) {  // :86-90
     while (i + 4 <= total) {  // :116
-      const uint32_t seq = uni(in_ld32<HAS_DICT>(in, i));
-      const uint32_t h = hash16(seq);
-      int32_t cand = uni((uint32_t)hc_head_get(t, h));  // insert(i) :96-103
-      if (lane == 0) {
-        hc_chain_set(t, i, cand);
-        hc_head_set(t, h, i);
+      const uint32_t p = i + lane;
+      const bool valid = p + 4 <= total;  // a prefix of the lanes
+      const uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
+      uint32_t seq = 0, h = 0;
+      if (valid) {
+        seq = in_ld32<HAS_DICT>(in, p);
+        h = hash16(seq);
       }
-      uint32_t best_len = 0, best_ref = 0, depth = 0;
-      while (cand >= 0 && depth < max_depth) {  // :123
+      uint64_t same = ballot(valid);
+      for (uint32_t bit = 0; bit < 16; bit++) {
+        const bool set = (h >> bit) & 1u;
+        const uint64_t m = ballot(set);
+        same &= set ? m : ~m;
+      }
+      if (!valid) same = 0;
+      const uint64_t earlier = same & ((1ull << lane) - 1ull);
+      const uint64_t later = same & ~((2ull << lane) - 1ull);
+      int32_t pred = -1;  // insert(p): the bucket's head as position p sees it (:96-103)
+      if (valid) pred = earlier ? (int32_t)(i + 63u - (uint32_t)__builtin_clzll(earlier)) : hc_head_get(t, h);
+      wchain[lane] = (uint32_t)(pred + 1);
+
+      // ---- chain walks, all lanes in lockstep (:123-147)
+      int32_t cand = pred;
+      uint32_t depth = 0, best_len = 0, best_ref = 0;
+      bool done = !valid;
+      uint32_t W = kWave;  // lowest lane known to hold a match
+      for (;;) {
+        const bool act = !done && lane <= W && cand >= 0 && depth < max_depth;
+        if (!act) done = true;
+        if (ballot(act) == 0) break;
         const uint32_t c = (uint32_t)cand;
-        const int32_t next = uni((uint32_t)hc_chain_get(t, c));
-        if (i - c <= 0xFFFFu) {  // far candidates only consume depth (:125-129)
-          if (uni(in_ld32<HAS_DICT>(in, c)) == seq) {
-            uint32_t ml = 4 + hc_match_len<HAS_DICT>(in, i + 4, c + 4, total, lane);
-            if (ml > best_len) {  // strictly longer: the nearest candidate wins ties (:137)
-              best_len = ml;
-              best_ref = c;
-              if (i + best_len == total) break;  // :140-142
-            }
-          }
+        int32_t next = -1;
+        uint32_t cseq = 0;
+        bool near = false;
+        if (act) {
+          next = c >= i ? (int32_t)wchain[c - i] - 1 : hc_chain_get(t, c);
+          near = p - c <= 0xFFFFu;  // far candidates only consume depth (:125-129)
+          if (near) cseq = in_ld32<HAS_DICT>(in, c);
         }
-        cand = next;
-        depth++;
+        bool m4 = act && near && cseq == seq;
+        // a lane with a 4-byte hit holds a match: lanes above the lowest such lane no longer matter
+        const uint64_t hitm = ballot(m4);
+        if (hitm) {
+          const uint32_t Wc = (uint32_t)__builtin_ctzll(hitm);
+          if (Wc < W) W = Wc;
+        }
+        m4 = m4 && lane <= W;
+        uint32_t ml = 0;
+        bool more = false;
+        if (m4) ml = hc_lane_len<HAS_DICT>(in, p, c, total, more);
+        for (uint64_t lm = ballot(more); lm; lm &= lm - 1) {  // long runs: the whole wavefront measures, 512 bytes per step
+          const uint32_t L = (uint32_t)__builtin_ctzll(lm);
+          const uint32_t cL = rdlane(c, L), lenL = rdlane(ml, L);
+          const uint32_t full = lenL + hc_match_len<HAS_DICT>(in, i + L + lenL, cL + lenL, total, lane);
+          if (lane == L) ml = full;
+        }
+        if (m4 && ml > best_len) {  // strictly longer: the nearest candidate wins ties (:137)
+          best_len = ml;
+          best_ref = c;
+          if (p + best_len == total) done = true;  // :140-142
+        }
+        if (act) {
+          cand = next;
+          depth++;
+        }
       }
-      if (best_len >= 4) {  // :150
-        // backward extension :155-161
-        uint32_t maxb = i - anchor < best_ref ? i - anchor : best_ref;
-        uint32_t b = 0;
-        while (b < maxb) {
-          uint32_t tt = b + lane;
-          bool same = tt < maxb && in_byte<HAS_DICT>(in, i - 1 - tt) == in_byte<HAS_DICT>(in, best_ref - 1 - tt);
-          uint64_t m = ballot(!same);
-          if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
-          b += kWave;
-        }
-        const uint32_t ms = i - b, ml = best_len + b;
-        op = emit_sequence(out, op, in.src + (anchor - D), ms - anchor, i - best_ref, ml, lane);
-        i = ms + ml;  // :173-174
-        anchor = i;
-        if (i + 4 > total) break;  // :176-178
-        hc_insert_range<HAS_DICT>(in, t, ms + 1, i - 4, lane);  // :180-185 (re-inserts included)
+
+      // ---- commit the inserts the reference has made by now: every lane up to the match
+      const uint32_t ncommit = W < kWave ? W + 1 : nvalid;
+      if (valid && lane < ncommit) {
+        hc_chain_set(t, p, pred);
+        const uint64_t inrange = ncommit < kWave ? (1ull << ncommit) - 1ull : ~0ull;
+        if (!(later & inrange)) hc_head_set(t, h, p);
+      }
+      if (W == kWave) {  // no match in this window (:190 for each position)
+        i += nvalid;
         continue;
       }
-      i++;  // :190
+      // ---- match at lane W (:150-187)
+      const uint32_t im = i + W;
+      const uint32_t blen = rdlane(best_len, W), bref = rdlane(best_ref, W);
+      const uint32_t maxb = im - anchor < bref ? im - anchor : bref;
+      uint32_t b = 0;
+      while (b < maxb) {  // backward extension :155-161
+        const uint32_t tt = b + lane;
+        const bool eq = tt < maxb && in_byte<HAS_DICT>(in, im - 1 - tt) == in_byte<HAS_DICT>(in, bref - 1 - tt);
+        const uint64_t m = ballot(!eq);
+        if (m) { b += (uint32_t)__builtin_ctzll(m); break; }
+        b += kWave;
+      }
+      const uint32_t ms = im - b, ml = blen + b;
+      op = emit_sequence(out, op, in.src + (anchor - D), ms - anchor, im - bref, ml, lane);
+      i = ms + ml;  // :173-174
+      anchor = i;
+      if (i + 4 > total) break;  // :176-178
+      hc_insert_range<HAS_DICT>(in, t, ms + 1, i - 4, lane);  // :180-185 (re-inserts included)
     }
   }
   const uint32_t last = total - anchor;  // :193-196
@@ -175,8 +256,10 @@ struct HcScratch {
 template <bool HAS_DICT>
 __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t max_depth, HcScratch sc,
                                                         uint32_t *counter) {
+  __shared__ uint32_t s_wchain[4][kWave];
   const uint32_t lane = lane_id();
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  lds_u32 *wchain = (lds_u32 *)s_wchain[uni(threadIdx.x / kWave)];
   HcTables t;
   t.head = sc.tables + (size_t)slot * kHashEntries;
   t.chain = sc.chains + (size_t)slot * sc.chain_stride;
@@ -202,7 +285,7 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t ma
     uint32_t out_len = 0;
     int32_t st = (uint64_t)(in.total - in.D) > sc.chain_stride
                      ? (int32_t)LZ4MI_UNSUPPORTED_HERE
-                     : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, t, lane, out_len);
+                     : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, t, wchain, lane, out_len);
     if (lane == 0) {
       a.out_len[b] = out_len;
       a.status[b] = st;
