@@ -58,8 +58,8 @@ struct lz4mi_ctx {
   // per-block bookkeeping
   lz4mi::DevBuf comp, comp_len, status, stored_word, payload_addr, payload_len, record_size, rec_off,
       hashes, words, total;
-  // HC encoder chains
-  lz4mi::DevBuf hc_chain;
+  // HC encoder: per-slot position index (rank + sorted), bucket counters and floors
+  lz4mi::DevBuf hc_chain, hc_cnt, hc_floor;
 
   // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
   uint32_t shard_blocks = 0;

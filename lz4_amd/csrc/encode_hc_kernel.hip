@@ -1,71 +1,151 @@
 // LZ4HC block encoder for gfx950, byte-identical to lz4HcBlockCompressToWriter
 // (lib/src/hc/lz4_hc_block_encoder.dart:49-197): hash-chain search, depth-bounded, greedy.
 //
-// One wavefront per block works on the real head table (65536 x u32 per wavefront slot,
-// generation-tagged like the fast encoder's) and the real chain array (u32 per position) in
-// HBM/L2, so every quirk of the reference's chain (positions that are never inserted,
-// re-inserted positions that turn the chain into a cycle, far candidates that still consume
-// search depth, :125-129) is reproduced by construction.  Positions without a match are taken
-// 64 at a time (see encode_block_hc); the lanes also share the work inside one step: long match
-// lengths (512 bytes per step), the backward extension, sequence emission, and the interior
-// inserts after a match (:180-185), which go 64 positions per step with the in-step order
-// resolved in registers (a position links to the nearest earlier lane of its bucket, the last
-// lane of a bucket becomes its head).
-// A shared dictionary is inserted once per batch into a read-only head table and chain.
+// The reference keeps a head table and a chain array and walks the chain of a position's bucket
+// candidate by candidate.  A chain is nothing but "the earlier inserted positions of the same
+// bucket, nearest first", so this kernel replaces pointer chasing by a per-block index built in
+// parallel before the parse: every position of dict||src sorted by (bucket, position).  The
+// candidates of position p are then the entries just below p's own rank: a contiguous slice that
+// 64 lanes read and evaluate at once.  Three facts of the reference make that exact:
+//   * every position below the current one has been inserted, except the last three positions
+//     of each match (:180-185 stops at i-4; the parse resumes at i) and the last three of the
+//     dictionary: those entries carry a flag and are skipped without consuming search depth;
+//   * far candidates (> 65535 back) still consume depth (:125-129);
+//   * after a match that was extended backwards the interior loop re-inserts the positions
+//     ms+1..i that had already been inserted.  Working the head/chain updates through shows the
+//     result for a bucket with re-inserted positions j1 < .. < jm: head = jm, jm -> .. -> j1 -> jm,
+//     a cycle that cuts off everything older than j1.  Going round the cycle only repeats
+//     candidates (a repeat is never strictly longer, :137), so the bucket simply gets a floor:
+//     ranks below j1 are unreachable from then on.
+// Positions without a match are taken 64 at a time, one per lane, all lanes stepping through
+// their slices in lockstep; the first lane whose walk found a match is where the reference takes
+// its next match.  When only one or two lanes are still walking (text: a match at nearly every
+// position, long chains) the whole wavefront evaluates one position's slice, 64 candidates per
+// step.
 #include "api_common.h"
 #include "encode_common.h"
 
 namespace lz4mi {
 
-struct HcTables {
-  uint32_t *head;            // slot head table, entry = gen<<24 | (pos+1)
-  uint32_t *chain;           // slot chain, entry = pos+1 of the previous head (0 = none), index = pos - D
-  const uint32_t *dict_head; // shared: pos+1 (0 = none)
-  const uint32_t *dict_chain;// shared: index = pos (< D)
-  uint32_t gen;
-  uint32_t D;
+constexpr uint32_t kNoIns = 0x80000000u;  // index entry: this position is never inserted
+
+struct HcIndex {
+  uint32_t *cnt;     // 65536 bucket counters, all zero between blocks
+  uint32_t *floor_;  // 65536: lowest rank of the bucket a walk can still reach
+  uint32_t *rank;    // per position of dict||src
+  uint32_t *sorted;  // per rank: position (| kNoIns)
 };
 
-__device__ __forceinline__ int32_t hc_head_get(const HcTables &t, uint32_t h) {
-  uint32_t e = __hip_atomic_load(t.head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if ((e >> kPosBits) == t.gen) return (int32_t)(e & kPosMask) - 1;
-  if (t.dict_head) return (int32_t)t.dict_head[h] - 1;
-  return -1;
+// Arrays of a slot are rewritten for every block by the wavefront that owns the slot; workgroup
+// scope keeps the accesses out of the per-CU L1 (no stale lines from the previous block).
+__device__ __forceinline__ uint32_t xld(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ void hc_head_set(const HcTables &t, uint32_t h, uint32_t pos) {
-  __hip_atomic_store(t.head + h, (t.gen << kPosBits) | (pos + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ int32_t hc_chain_get(const HcTables &t, uint32_t pos) {
-  if (pos < t.D) return (int32_t)t.dict_chain[pos] - 1;
-  return (int32_t)__hip_atomic_load(t.chain + (pos - t.D), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - 1;
-}
-__device__ __forceinline__ void hc_chain_set(const HcTables &t, uint32_t pos, int32_t prev) {
-  __hip_atomic_store(t.chain + (pos - t.D), (uint32_t)(prev + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+__device__ __forceinline__ void xst(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// insert(pos) for pos = lo..hi ascending (:96-103), 64 positions per step.
+// lanes (among the valid ones) whose 16-bit hash equals this lane's
+__device__ __forceinline__ uint64_t same_bucket(uint32_t h, bool valid) {
+  uint64_t same = ballot(valid);
+  for (uint32_t bit = 0; bit < 16; bit++) {
+    const bool set = (h >> bit) & 1u;
+    const uint64_t m = ballot(set);
+    same &= set ? m : ~m;
+  }
+  return valid ? same : 0ull;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_max(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+  return o > v ? o : v;
+}
+// maximum over the 64 lanes (wave-uniform result): row shifts, then the two row broadcasts
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+  v = dpp_max<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_max<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_max<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_max<0x118, 0xF>(v);  // row_shr:8 -> lane 15 of every row holds the row's maximum
+  v = dpp_max<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_max<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return rdlane(v, kWave - 1);
+}
+
+// Index of one block: counting sort of the positions 0 .. T-1 by bucket, stable in position.
 template <bool HAS_DICT>
-__device__ __forceinline__ void hc_insert_range(const EncIn &in, const HcTables &t, uint32_t lo, uint32_t hi,
-                                                uint32_t lane) {
-  for (uint32_t base = lo; base <= hi; base += kWave) {
-    const uint32_t p = base + lane;
-    const bool valid = p <= hi;
-    const uint64_t vmask = ballot(valid);
-    uint32_t h = 0;
-    if (valid) h = hash16(in_ld32<HAS_DICT>(in, p));
-    uint64_t same = vmask;
-    for (uint32_t bit = 0; bit < 16; bit++) {
-      bool set = (h >> bit) & 1u;
-      uint64_t m = ballot(set);
-      same &= set ? m : ~m;
+__device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x, uint32_t T, uint32_t lane) {
+  const uint32_t D = HAS_DICT ? in.D : 0u;
+  constexpr uint32_t U = 4;  // chunks of 64 positions in flight, so that their memory round trips overlap
+  // 1: bucket sizes; rank[p] = number of earlier positions in p's bucket
+  for (uint32_t base = 0; base < T; base += U * kWave) {
+    uint32_t h[U], old[U], last[U], before[U];
+    bool valid[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t p = base + u * kWave + lane;
+      valid[u] = p < T;
+      h[u] = valid[u] ? hash16(in_ld32<HAS_DICT>(in, p)) : 0u;
     }
-    if (valid) {
-      const uint64_t earlier = same & ((1ull << lane) - 1ull);
-      const uint64_t later = same & ~((2ull << lane) - 1ull);
-      int32_t link = earlier ? (int32_t)(base + 63u - (uint32_t)__builtin_clzll(earlier)) : hc_head_get(t, h);
-      hc_chain_set(t, p, link);
-      if (!later) hc_head_set(t, h, p);
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint64_t same = same_bucket(h[u], valid[u]);
+      last[u] = same ? 63u - (uint32_t)__builtin_clzll(same) : lane;
+      before[u] = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+      old[u] = 0;
+      if (valid[u] && lane == last[u])  // chunks are issued in position order, so a bucket met twice still counts in order
+        old[u] = __hip_atomic_fetch_add(x.cnt + h[u], (uint32_t)__builtin_popcountll(same), __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t o = (uint32_t)__shfl((int)old[u], (int)last[u]);
+      if (valid[u]) xst(x.rank + base + u * kWave + lane, o + before[u]);
+    }
+  }
+  // 2: exclusive prefix sum of the sizes = first rank of every bucket; counters back to zero
+  uint32_t carry = 0;
+  for (uint32_t k = 0; k < kHashEntries; k += U * kWave) {
+    uint32_t v[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) v[u] = xld(x.cnt + k + u * kWave + lane);
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      uint32_t inc = v[u];
+      for (uint32_t d = 1; d < kWave; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, (int)d);
+        if (lane >= d) inc += o;
+      }
+      xst(x.floor_ + k + u * kWave + lane, carry + inc - v[u]);
+      xst(x.cnt + k + u * kWave + lane, 0u);
+      carry += rdlane(inc, kWave - 1);
+    }
+  }
+  // 3: scatter
+  for (uint32_t base = 0; base < T; base += U * kWave) {
+    uint32_t h[U], ord[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t p = base + u * kWave + lane;
+      h[u] = p < T ? hash16(in_ld32<HAS_DICT>(in, p)) : 0u;
+      ord[u] = p < T ? xld(x.rank + p) : 0u;
+    }
+    uint32_t st[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) st[u] = xld(x.floor_ + h[u]);
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t p = base + u * kWave + lane;
+      if (p < T) {
+        xst(x.sorted + st[u] + ord[u], p);
+        xst(x.rank + p, st[u] + ord[u]);
+      }
+    }
+  }
+  // the last three dictionary positions are never inserted (:105-109 stops at dictLength - 4)
+  if (HAS_DICT && D != 0) {
+    const uint32_t q = D - 1 - lane;
+    if (lane < 3 && lane < D && q < T) xst(x.sorted + xld(x.rank + q), q | kNoIns);
   }
 }
 
@@ -98,10 +178,10 @@ __device__ __forceinline__ uint32_t hc_match_len(const EncIn &in, uint32_t p, ui
 }
 
 // Equal bytes (>= 4, the caller has compared the first four) of p.. and c.. (c < p), measured by
-// one lane up to kLaneCmp bytes; `more` says the run was still going at that point.
-constexpr uint32_t kLaneCmp = 64;
+// one lane up to `limit` bytes; `more` says the run was still going at that point.
 template <bool HAS_DICT>
-__device__ __forceinline__ uint32_t hc_lane_len(const EncIn &in, uint32_t p, uint32_t c, uint32_t total, bool &more) {
+__device__ __forceinline__ uint32_t hc_lane_len(const EncIn &in, uint32_t p, uint32_t c, uint32_t total,
+                                                uint32_t limit, bool &more) {
   uint32_t len = 4;
   more = false;
   for (;;) {
@@ -109,7 +189,7 @@ __device__ __forceinline__ uint32_t hc_lane_len(const EncIn &in, uint32_t p, uin
       const uint32_t x = in_ld32<HAS_DICT>(in, p + len) ^ in_ld32<HAS_DICT>(in, c + len);
       if (x) return len + ((uint32_t)__builtin_ctz(x) >> 3);
       len += 4;
-      if (len >= kLaneCmp) { more = p + len < total; return len; }
+      if (len >= limit) { more = p + len < total; return len; }
     } else {
       while (p + len < total && in_byte<HAS_DICT>(in, p + len) == in_byte<HAS_DICT>(in, c + len)) len++;
       return len;
@@ -117,18 +197,56 @@ __device__ __forceinline__ uint32_t hc_lane_len(const EncIn &in, uint32_t p, uin
   }
 }
 
-// The reference visits positions one by one (:116-190), but as long as no match is taken the
-// work at consecutive positions is independent: position p links to the latest earlier position
-// of its bucket and walks that chain.  A wavefront therefore takes 64 consecutive positions at a
-// time, one per lane: links inside the window are resolved in registers (nearest earlier lane of
-// the same bucket, kept in a 64-entry LDS array for the walks), every lane walks its chain in
-// lockstep, and the first lane whose walk found a match is the position where the reference
-// takes its next match.  Only the lanes up to that one are then committed to the head table and
-// chain; the later lanes' work is discarded, so the tables never hold an insert the reference
-// would not have made at that point.
+// Lanes flagged `more` hold a run that was still going after their own compare: the whole
+// wavefront finishes those, one at a time.
+template <bool HAS_DICT>
+__device__ __forceinline__ void hc_finish_long(const EncIn &in, uint32_t p_uniform_base, bool per_lane_p, uint32_t c,
+                                               uint32_t &ml, bool more, uint32_t total, uint32_t lane) {
+  for (uint64_t lm = ballot(more); lm; lm &= lm - 1) {
+    const uint32_t L = (uint32_t)__builtin_ctzll(lm);
+    const uint32_t pL = per_lane_p ? p_uniform_base + L : p_uniform_base;
+    const uint32_t cL = rdlane(c, L), lenL = rdlane(ml, L);
+    const uint32_t full = lenL + hc_match_len<HAS_DICT>(in, pL + lenL, cL + lenL, total, lane);
+    if (lane == L) ml = full;
+  }
+}
+
+// The rest of one position's walk with the whole wavefront: 64 index entries per step, lane d
+// looks at rank idx - d.  All arguments are wave-uniform.
+template <bool HAS_DICT>
+__device__ __forceinline__ void hc_eval_slice(const EncIn &in, const HcIndex &x, uint32_t P, uint32_t seq, int32_t idx,
+                                              int32_t lo, uint32_t depth, uint32_t max_depth, uint32_t total,
+                                              uint32_t lane, uint32_t &best_len, uint32_t &best_ref) {
+  while (idx >= lo && depth < max_depth) {
+    const int32_t my = idx - (int32_t)lane;
+    const uint32_t e = my >= lo ? xld(x.sorted + my) : kNoIns;
+    const bool ins = !(e & kNoIns);
+    const uint64_t insm = ballot(ins);
+    const uint32_t ordinal = (uint32_t)__builtin_popcountll(insm & ((1ull << lane) - 1ull));
+    const bool take = ins && depth + ordinal < max_depth;  // :123 depth bound, flagged entries are not on the chain
+    const uint32_t c = e & kPosMask;
+    const bool near = take && P - c <= 0xFFFFu;  // :125-129
+    const uint32_t cseq = near ? in_ld32<HAS_DICT>(in, c) : 0u;
+    const bool m4 = near && cseq == seq;
+    uint32_t ml = 0;
+    bool more = false;
+    if (m4) ml = hc_lane_len<HAS_DICT>(in, P, c, total, 512u, more);
+    hc_finish_long<HAS_DICT>(in, P, false, c, ml, more, total, lane);
+    const uint32_t mx = wave_max(m4 ? ml : 0u);
+    if (mx > best_len) {  // strictly longer; among equals the nearest (lowest lane) was first (:137)
+      const uint32_t Lb = (uint32_t)__builtin_ctzll(ballot(m4 && ml == mx));
+      best_len = mx;
+      best_ref = rdlane(c, Lb);
+      if (P + best_len == total) return;  // :140-142 (nothing later can be strictly longer)
+    }
+    depth += (uint32_t)__builtin_popcountll(insm);
+    idx -= (int32_t)kWave;
+  }
+}
+
 template <bool HAS_DICT>
 __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out, uint32_t cap, uint32_t max_depth,
-                                                   HcTables t, lds_u32 *wchain, uint32_t lane, uint32_t &out_len) {
+                                                   const HcIndex x, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t n = total - D;
@@ -139,47 +257,51 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
   uint32_t anchor = D, i = D, op = 0;
 
   if (n >= 4) {  // :86-90
+    hc_build_index<HAS_DICT>(in, x, total - 3, lane);
     while (i + 4 <= total) {  // :116
       const uint32_t p = i + lane;
       const bool valid = p + 4 <= total;  // a prefix of the lanes
       const uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
-      uint32_t seq = 0, h = 0;
+      uint32_t seq = 0;
+      int32_t idx = -1, lo = 0;
       if (valid) {
         seq = in_ld32<HAS_DICT>(in, p);
-        h = hash16(seq);
+        lo = (int32_t)xld(x.floor_ + hash16(seq));
+        idx = (int32_t)xld(x.rank + p) - 1;
       }
-      uint64_t same = ballot(valid);
-      for (uint32_t bit = 0; bit < 16; bit++) {
-        const bool set = (h >> bit) & 1u;
-        const uint64_t m = ballot(set);
-        same &= set ? m : ~m;
-      }
-      if (!valid) same = 0;
-      const uint64_t earlier = same & ((1ull << lane) - 1ull);
-      const uint64_t later = same & ~((2ull << lane) - 1ull);
-      int32_t pred = -1;  // insert(p): the bucket's head as position p sees it (:96-103)
-      if (valid) pred = earlier ? (int32_t)(i + 63u - (uint32_t)__builtin_clzll(earlier)) : hc_head_get(t, h);
-      wchain[lane] = (uint32_t)(pred + 1);
-
-      // ---- chain walks, all lanes in lockstep (:123-147)
-      int32_t cand = pred;
       uint32_t depth = 0, best_len = 0, best_ref = 0;
       bool done = !valid;
       uint32_t W = kWave;  // lowest lane known to hold a match
       for (;;) {
-        const bool act = !done && lane <= W && cand >= 0 && depth < max_depth;
+        const bool act = !done && lane <= W && idx >= lo && depth < max_depth;
         if (!act) done = true;
-        if (ballot(act) == 0) break;
-        const uint32_t c = (uint32_t)cand;
-        int32_t next = -1;
-        uint32_t cseq = 0;
-        bool near = false;
-        if (act) {
-          next = c >= i ? (int32_t)wchain[c - i] - 1 : hc_chain_get(t, c);
-          near = p - c <= 0xFFFFu;  // far candidates only consume depth (:125-129)
-          if (near) cseq = in_ld32<HAS_DICT>(in, c);
+        const uint64_t am = ballot(act);
+        if (am == 0) break;
+        if (__builtin_popcountll(am) <= 2) {
+          // few walkers left: the wavefront finishes the lowest one, 64 candidates per step
+          const uint32_t L = (uint32_t)__builtin_ctzll(am);
+          uint32_t bl = rdlane(best_len, L), br = rdlane(best_ref, L);
+          hc_eval_slice<HAS_DICT>(in, x, i + L, rdlane(seq, L), (int32_t)rdlane((uint32_t)idx, L),
+                                  (int32_t)rdlane((uint32_t)lo, L), rdlane(depth, L), max_depth, total, lane, bl, br);
+          if (lane == L) {
+            best_len = bl;
+            best_ref = br;
+            done = true;
+          }
+          if (bl >= 4 && L < W) W = L;
+          continue;
         }
-        bool m4 = act && near && cseq == seq;
+        // one candidate per walking lane
+        uint32_t e = kNoIns;
+        if (act) {
+          e = xld(x.sorted + idx);
+          idx--;
+        }
+        const bool cnd = act && !(e & kNoIns);  // flagged entries are not on the chain
+        const uint32_t c = e & kPosMask;
+        const bool near = cnd && p - c <= 0xFFFFu;  // far candidates only consume depth (:125-129)
+        const uint32_t cseq = near ? in_ld32<HAS_DICT>(in, c) : 0u;
+        bool m4 = near && cseq == seq;
         // a lane with a 4-byte hit holds a match: lanes above the lowest such lane no longer matter
         const uint64_t hitm = ballot(m4);
         if (hitm) {
@@ -189,30 +311,14 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
         m4 = m4 && lane <= W;
         uint32_t ml = 0;
         bool more = false;
-        if (m4) ml = hc_lane_len<HAS_DICT>(in, p, c, total, more);
-        for (uint64_t lm = ballot(more); lm; lm &= lm - 1) {  // long runs: the whole wavefront measures, 512 bytes per step
-          const uint32_t L = (uint32_t)__builtin_ctzll(lm);
-          const uint32_t cL = rdlane(c, L), lenL = rdlane(ml, L);
-          const uint32_t full = lenL + hc_match_len<HAS_DICT>(in, i + L + lenL, cL + lenL, total, lane);
-          if (lane == L) ml = full;
-        }
+        if (m4) ml = hc_lane_len<HAS_DICT>(in, p, c, total, 64u, more);
+        hc_finish_long<HAS_DICT>(in, i, true, c, ml, more, total, lane);
         if (m4 && ml > best_len) {  // strictly longer: the nearest candidate wins ties (:137)
           best_len = ml;
           best_ref = c;
           if (p + best_len == total) done = true;  // :140-142
         }
-        if (act) {
-          cand = next;
-          depth++;
-        }
-      }
-
-      // ---- commit the inserts the reference has made by now: every lane up to the match
-      const uint32_t ncommit = W < kWave ? W + 1 : nvalid;
-      if (valid && lane < ncommit) {
-        hc_chain_set(t, p, pred);
-        const uint64_t inrange = ncommit < kWave ? (1ull << ncommit) - 1ull : ~0ull;
-        if (!(later & inrange)) hc_head_set(t, h, p);
+        if (cnd) depth++;
       }
       if (W == kWave) {  // no match in this window (:190 for each position)
         i += nvalid;
@@ -235,7 +341,20 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
       i = ms + ml;  // :173-174
       anchor = i;
       if (i + 4 > total) break;  // :176-178
-      hc_insert_range<HAS_DICT>(in, t, ms + 1, i - 4, lane);  // :180-185 (re-inserts included)
+      // :180-185.  Positions ms+1 .. im are inserted a second time: their buckets get a floor at
+      // the lowest of them (highest positions first, so the lowest one writes last).
+      for (uint32_t hi = im; hi > ms; hi -= (hi - ms < kWave ? hi - ms : kWave)) {
+        const bool v = hi - ms > lane;  // position hi - lane is above ms
+        const uint32_t j = hi - lane;
+        const uint32_t hj = v ? hash16(in_ld32<HAS_DICT>(in, j)) : 0u;
+        const uint64_t same = same_bucket(hj, v);
+        if (v && !(same & ~((2ull << lane) - 1ull))) xst(x.floor_ + hj, xld(x.rank + j));
+      }
+      // the last three positions of the match are never inserted
+      {
+        const uint32_t q = i - 3 + lane;
+        if (lane < 3 && q + 4 <= total) xst(x.sorted + xld(x.rank + q), q | kNoIns);
+      }
     }
   }
   const uint32_t last = total - anchor;  // :193-196
@@ -245,81 +364,38 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
 }
 
 struct HcScratch {
-  uint32_t *tables;      // nslots * 65536
-  uint32_t *slot_gen;
-  uint32_t *chains;      // nslots * chain_stride
-  uint64_t chain_stride;
-  const uint32_t *dict_head;
-  const uint32_t *dict_chain;
+  uint32_t *cnt;       // nslots * 65536, zero
+  uint32_t *floor_;    // nslots * 65536
+  uint32_t *index;     // nslots * 2 * stride: rank[stride], sorted[stride]
+  uint64_t stride;     // positions per slot
 };
 
 template <bool HAS_DICT>
 __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t max_depth, HcScratch sc,
                                                         uint32_t *counter) {
-  __shared__ uint32_t s_wchain[4][kWave];
   const uint32_t lane = lane_id();
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
-  lds_u32 *wchain = (lds_u32 *)s_wchain[uni(threadIdx.x / kWave)];
-  HcTables t;
-  t.head = sc.tables + (size_t)slot * kHashEntries;
-  t.chain = sc.chains + (size_t)slot * sc.chain_stride;
-  t.dict_head = HAS_DICT ? sc.dict_head : nullptr;
-  t.dict_chain = sc.dict_chain;
-  t.D = HAS_DICT ? a.dict_len : 0u;
-  uint32_t gen = uni(sc.slot_gen[slot]);
+  HcIndex x;
+  x.cnt = sc.cnt + (size_t)slot * kHashEntries;
+  x.floor_ = sc.floor_ + (size_t)slot * kHashEntries;
+  x.rank = sc.index + (size_t)slot * 2 * sc.stride;
+  x.sorted = x.rank + sc.stride;
   EncIn in;
   in.dict = a.dict;
-  in.D = a.dict_len;
+  in.D = HAS_DICT ? a.dict_len : 0u;
   for (;;) {
     const uint32_t b = next_block(counter, lane);
     if (b >= a.nblocks) break;
-    if (++gen > kGenMax) {
-      for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(t.head + k) = make_uint4(0, 0, 0, 0);
-      gen = 1;
-    }
-    t.gen = gen;
     in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
     in.total = in.D + uni(block_src_len(a, b));
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;
-    int32_t st = (uint64_t)(in.total - in.D) > sc.chain_stride
-                     ? (int32_t)LZ4MI_UNSUPPORTED_HERE
-                     : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, t, wchain, lane, out_len);
+    int32_t st = (uint64_t)in.total > sc.stride ? (int32_t)LZ4MI_UNSUPPORTED_HERE
+                                                : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, x, lane, out_len);
     if (lane == 0) {
       a.out_len[b] = out_len;
       a.status[b] = st;
-    }
-  }
-  if (lane == 0) sc.slot_gen[slot] = gen;
-}
-
-// Dictionary priming (:105-109): one wavefront inserts every dictionary position in order
-// into the shared head table / chain (entries are pos+1, 0 = none; no generation tag).
-__global__ __launch_bounds__(64) void hc_dict_prime_kernel(const uint8_t *dict, uint32_t D, uint32_t *dict_head,
-                                                           uint32_t *dict_chain) {
-  const uint32_t lane = lane_id();
-  if (D < 4) return;
-  const uint32_t hi = D - 4;
-  for (uint32_t base = 0; base <= hi; base += kWave) {
-    const uint32_t p = base + lane;
-    const bool valid = p <= hi;
-    const uint64_t vmask = ballot(valid);
-    uint32_t h = 0;
-    if (valid) h = hash16(ld32(dict + p));
-    uint64_t same = vmask;
-    for (uint32_t bit = 0; bit < 16; bit++) {
-      bool set = (h >> bit) & 1u;
-      uint64_t m = ballot(set);
-      same &= set ? m : ~m;
-    }
-    if (valid) {
-      const uint64_t earlier = same & ((1ull << lane) - 1ull);
-      const uint64_t later = same & ~((2ull << lane) - 1ull);
-      uint32_t link = earlier ? base + 63u - (uint32_t)__builtin_clzll(earlier) + 1u
-                              : __hip_atomic_load(dict_head + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      dict_chain[p] = link;
-      if (!later) __hip_atomic_store(dict_head + h, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
 }
@@ -333,39 +409,26 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
     a.dict += a.dict_len - 65535;
     a.dict_len = 65535;
   }
-  // chain capacity: the largest block this batch can contain
+  // index capacity: dictionary plus the largest block this batch can contain
   uint64_t max_len = a.src_len ? (a.dst_cap_uniform ? a.dst_cap_uniform : (4u << 20)) : a.src_len_uniform;
   if (max_len > kPosMask) max_len = kPosMask;
-  const uint64_t stride = round_up(max_len + 64, 64);
-  const uint64_t budget = 8ull << 30;  // bytes of chain scratch
+  const uint64_t stride = round_up(max_len + a.dict_len + 64, 64);
+  const uint64_t budget = 8ull << 30;  // bytes of index scratch
   uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);
-  while (slots > 4 && (uint64_t)slots * stride * 4 > budget) slots -= 4;
-  // head tables are shared with the fast encoder's slots
-  if (slots > c->nslots) {
+  while (slots > 4 && (uint64_t)slots * stride * 8 > budget) slots -= 4;
+  const size_t tbl = (size_t)slots * kHashEntries * sizeof(uint32_t);
+  if (tbl > c->hc_cnt.cap) {  // counters must start at zero; the kernel leaves them at zero
     LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-    LZ4MI_HIP(c, c->tables.ensure((size_t)slots * kHashEntries * sizeof(uint32_t)));
-    LZ4MI_HIP(c, c->slot_gen.ensure((size_t)slots * sizeof(uint32_t)));
-    LZ4MI_HIP(c, hipMemsetAsync(c->tables.p, 0, (size_t)slots * kHashEntries * sizeof(uint32_t), c->stream));
-    LZ4MI_HIP(c, hipMemsetAsync(c->slot_gen.p, 0, (size_t)slots * sizeof(uint32_t), c->stream));
-    c->nslots = slots;
+    LZ4MI_HIP(c, c->hc_cnt.ensure(tbl));
+    LZ4MI_HIP(c, hipMemsetAsync(c->hc_cnt.p, 0, c->hc_cnt.cap, c->stream));
   }
-  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 4));
+  LZ4MI_HIP(c, c->hc_floor.ensure(tbl));
+  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 8));
   HcScratch sc;
-  sc.tables = c->tables.as<uint32_t>();
-  sc.slot_gen = c->slot_gen.as<uint32_t>();
-  sc.chains = c->hc_chain.as<uint32_t>();
-  sc.chain_stride = stride;
-  sc.dict_head = nullptr;
-  sc.dict_chain = nullptr;
-  if (a.dict_len) {
-    LZ4MI_HIP(c, c->dict_table.ensure(kHashEntries * sizeof(uint32_t)));
-    LZ4MI_HIP(c, c->dict_copy.ensure((size_t)65536 * sizeof(uint32_t)));
-    LZ4MI_HIP(c, hipMemsetAsync(c->dict_table.p, 0, kHashEntries * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(hc_dict_prime_kernel, dim3(1), dim3(64), 0, c->stream, a.dict, a.dict_len,
-                       c->dict_table.as<uint32_t>(), c->dict_copy.as<uint32_t>());
-    sc.dict_head = c->dict_table.as<uint32_t>();
-    sc.dict_chain = c->dict_copy.as<uint32_t>();
-  }
+  sc.cnt = c->hc_cnt.as<uint32_t>();
+  sc.floor_ = c->hc_floor.as<uint32_t>();
+  sc.index = c->hc_chain.as<uint32_t>();
+  sc.stride = stride;
   uint32_t *counter = c->d_counters + 2;
   LZ4MI_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
   uint32_t grid = (a.nblocks + 3) / 4;

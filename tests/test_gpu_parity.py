@@ -533,3 +533,29 @@ def test_hc_frame_with_dictionary_vs_oracle(lz, oracle):
     assert len(lz.lz4FrameEncodeWithOptions(ramp(1 << 20), options=Lz4FrameOptions(
         blockSize=Lz4FrameBlockSize.k64KB, compression=Lz4FrameCompression.hc))) \
         == golden()["encoder_sizes_repeating_1MiB"]["frame64k_hc"]
+
+
+def test_hc_encoder_chain_quirks_fuzz_vs_oracle(lz, oracle):
+    """Inputs built to hit the corners of the reference's chain: matches extended backwards
+    (positions inserted twice), runs of never-inserted positions, far candidates that only
+    consume depth, and depth limits smaller than the bucket population."""
+    from lz4_amd import Lz4CompressionLevel, Lz4HcOptions
+    rng = np.random.default_rng(20261111)
+    cases = []
+    for k in range(40):
+        n = int(rng.integers(200, 24000))
+        alpha = int(rng.choice([2, 3, 4, 8, 16, 64]))
+        a = rng.integers(0, alpha, size=n, dtype=np.uint8)
+        if k % 3 == 0:  # splice in copies at random offsets so that long matches start mid-run
+            for _ in range(int(rng.integers(1, 30))):
+                ln = int(rng.integers(4, 400)); s0 = int(rng.integers(0, n - 1)); d0 = int(rng.integers(0, n - 1))
+                ln = min(ln, n - s0, n - d0)
+                a[d0:d0 + ln] = a[s0:s0 + ln].copy()
+        cases.append(a.tobytes())
+    far = bytes(rng.integers(0, 256, size=300, dtype=np.uint8))
+    cases.append(far + bytes(rng.integers(0, 256, size=70000, dtype=np.uint8)) + far + far[:100])  # > 65535 back
+    cases.append((b"abcdefgh" * 40 + bytes(rng.integers(0, 256, size=50, dtype=np.uint8))) * 60)
+    for idx, data in enumerate(cases):
+        for depth in ((1, 3, 64) if idx % 2 else (2, 7, 1000)):
+            got = lz.lz4Compress(data, level=Lz4CompressionLevel.hc, hcOptions=Lz4HcOptions(maxSearchDepth=depth))
+            assert got == oracle.block_compress_hc(data, max_search_depth=depth), (idx, len(data), depth)
