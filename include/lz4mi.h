@@ -59,7 +59,7 @@ enum {
   LZ4MI_BACKEND = 70,                /* HIP runtime failure; see lz4mi_last_backend_error */
   LZ4MI_DST_TOO_SMALL = 71,          /* caller's destination buffer cannot hold the result */
   LZ4MI_NEED_DICT = 72,              /* lz4mi_frame_decode_next: call again with the dictionary */
-  LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent-block encode on device) */
+  LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent blocks through the shard calls, blocks of 16 MiB and more) */
 };
 
 /* Dart exception class name / message for a status (static strings). */
@@ -196,7 +196,7 @@ int32_t lz4mi_frame_encode(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
                            const lz4mi_frame_options *o, const uint8_t *dict, size_t dict_len,
                            uint8_t *dst, size_t cap, size_t *out_len);
 
-/* Same, device-resident source and destination (independent blocks only).
+/* Same, device-resident source and destination (independent or linked blocks).
  * first_block_index/emit_header/emit_trailer let N ranks each encode a
  * contiguous block range of one frame: rank r passes its shard, gets per-block
  * stored sizes in d_stored_sizes, and after the sizes have been exchanged

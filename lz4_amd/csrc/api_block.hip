@@ -172,7 +172,7 @@ int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a_in, int64_t accelerat
   sc.slot_gen = c->slot_gen.as<uint32_t>();
   sc.nslots = c->nslots;
   sc.dict_table = nullptr;
-  if (a.dict_len) {
+  if (a.dict_len && !a.linked) {
     LZ4MI_HIP(c, c->dict_table.ensure(kHashEntries * sizeof(uint32_t)));
     sc.dict_table = c->dict_table.as<uint32_t>();
     launch_dict_prime(a.dict, a.dict_len, sc.dict_table, c->stream);
@@ -219,6 +219,7 @@ static void to_args(const lz4mi_batch *b, BatchArgs &a) {
   a.nblocks = b->nblocks;
   a.out_len = b->d_out_len;
   a.status = b->d_status;
+  a.linked = 0;
 }
 
 }  // namespace lz4mi

@@ -98,6 +98,7 @@ int32_t shard_compress(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4
   a.dst_cap_uniform = (uint32_t)stride;
   a.dict = d_dict;
   a.dict_len = d_dict ? dict_len : 0;
+  a.linked = o->block_independence ? 0u : 1u;
   a.nblocks = nb;
   a.out_len = c->comp_len.as<uint32_t>();
   a.status = c->status.as<int32_t>();
@@ -177,7 +178,7 @@ extern "C" int32_t lz4mi_frame_shard_compress(lz4mi_ctx *c, const uint8_t *d_src
   if (!c || !nblocks_out) return LZ4MI_RANGE;
   int32_t st = validate_options(o);
   if (st) return st;
-  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
+  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;  // a rank's first block would need the previous rank's bytes
   LZ4MI_HIP(c, hipSetDevice(c->device));
   st = shard_compress(c, d_src, n, o, d_dict, dict_len, nblocks_out);
   if (st) return st;
@@ -202,7 +203,6 @@ extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src,
   if (!c) return LZ4MI_RANGE;
   int32_t st = validate_options(o);
   if (st) return st;
-  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
   LZ4MI_HIP(c, hipSetDevice(c->device));
   if (cap < lz4mi_frame_bound((size_t)n, o)) return LZ4MI_DST_TOO_SMALL;
   uint8_t hdr[32];
@@ -241,7 +241,6 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   if (out_len) *out_len = 0;
   int32_t st = validate_options(o);
   if (st) return st;
-  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;
   LZ4MI_HIP(c, hipSetDevice(c->device));
   const size_t fb = lz4mi_frame_bound(n, o);
   LZ4MI_HIP(c, c->in.ensure(n + 16));

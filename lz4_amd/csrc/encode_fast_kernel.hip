@@ -155,7 +155,26 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + D, 0xF, 0xF, false);
 }
 
-template <bool HAS_DICT>
+// One re-hash step: table[hash] = position for up to 64 ascending positions.  Inserts go out as
+// plain stores (a store to a line that is not cached needs no fetch, an atomic does).  Positions
+// rise with the lane, so of the lanes of one instruction that share a bucket only the highest may
+// store: each lane max-claims a slot of a small LDS array with its lane number and looks at the
+// winner's hash.  Same hash: the winner is the bucket's highest lane.  Different hash (two buckets
+// met in one slot): undecided, those lanes fall back to the atomic max, which is always right.
+__device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_t hj, uint32_t value, bool live,
+                                            uint32_t lane) {
+  lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
+  if (live) (void)__hip_atomic_fetch_max(slot, lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  const uint32_t top = live ? *slot : lane + 1;
+  const uint32_t htop = (uint32_t)__shfl((int)hj, (int)(top - 1));
+  if (live) {
+    *slot = 0;
+    if (htop != hj) tbl_max(T + hj, value);
+    else if (top == lane + 1) tbl_store(T + hj, value);
+  }
+}
+
+template <bool HAS_DICT, bool LINKED>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
@@ -172,6 +191,13 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   PH_DECL
 
   if (n >= 4) {  // :74-78
+    if (LINKED && D >= 4) {  // :83-88, the block's own dictionary goes into its own table
+      for (uint32_t j0 = 0; j0 + 4 <= D; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        const bool live = j + 4 <= D;
+        insert_step(T, claim, live ? hash16(ld32(in.dict + j)) : 0u, gtag | (j + 1), live, lane);
+      }
+    }
     Win w = {lds, in.src, n, 0, 0};
     while (anchor + 4 <= total) {  // one iteration per sequence
       const uint32_t s = anchor - D;
@@ -196,9 +222,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         // gives one unconditional wait, which also covers the segment requested above.
         const uint32_t hx = valid ? h : 0u;
         const uint32_t e = tbl_load(T + hx);
-        const uint32_t ed = HAS_DICT ? dictT[hx] : 0u;
+        const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[hx] : 0u;
         if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
-        else if (HAS_DICT) ref = (int32_t)ed - 1;
+        else if (HAS_DICT && !LINKED) ref = (int32_t)ed - 1;
       }
       uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));  // >= 1, valid lanes form a prefix
 #ifdef LZ4MI_PROFILE
@@ -261,9 +287,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
             seq = rd32<HAS_DICT>(in, w, ik);
             h = hash16(seq);
             const uint32_t e = tbl_load(T + h);
-            const uint32_t ed = HAS_DICT ? dictT[h] : 0u;
+            const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[h] : 0u;
             if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
-            else if (HAS_DICT) ref = (int32_t)ed - 1;
+            else if (HAS_DICT && !LINKED) ref = (int32_t)ed - 1;
           }
           {  // same-bucket probes of this chunk, nearest earlier lane: 16 bit-plane votes
             uint64_t peers = valid ? ((1ull << lane) - 1ull) : 0ull;
@@ -396,25 +422,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         uint32_t lo = ms + 1;
         if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
         if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
-          // Inserts go out as plain stores (a store to a line that is not cached needs no fetch,
-          // an atomic does).  Positions rise with the lane, so of the lanes of one instruction that
-          // share a bucket only the highest may store: each lane max-claims a slot of a small LDS
-          // array with its lane number and looks at the winner's hash.  Same hash: the winner is
-          // the bucket's highest lane.  Different hash (two buckets met in one slot): undecided,
-          // those lanes fall back to the atomic max, which is always right.
           for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
             const uint32_t j = j0 + lane;
-            const uint32_t hj = hash16(w32(w, j - D));
-            const bool live = j <= hi;
-            lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
-            if (live) (void)__hip_atomic_fetch_max(slot, lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const uint32_t top = live ? *slot : lane + 1;
-            const uint32_t htop = (uint32_t)__shfl((int)hj, (int)(top - 1));
-            if (live) {
-              *slot = 0;
-              if (htop != hj) tbl_max(T + hj, gtag | (j + 1));
-              else if (top == lane + 1) tbl_store(T + hj, gtag | (j + 1));
-            }
+            insert_step(T, claim, hash16(w32(w, j - D)), gtag | (j + 1), j <= hi, lane);
           }
         } else {
           for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
@@ -436,7 +446,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   return LZ4MI_OK;
 }
 
-template <bool HAS_DICT>
+template <bool HAS_DICT, bool LINKED>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t sh, EncodeScratch sc,
                                                           uint32_t *counter) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
@@ -473,11 +483,15 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
       gen = 1;
     }
     in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    if (LINKED) {  // lz4_frame_encoder.dart:176-180; the encoder keeps the last 65535 bytes (:50-61)
+      in.dict = b == 0 ? a.dict : in.src - 65535;
+      in.D = b == 0 ? a.dict_len : 65535u;
+    }
     in.total = in.D + uni(block_src_len(a, b));
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;
-    int32_t st = encode_block_fast<HAS_DICT>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane,
+    int32_t st = encode_block_fast<HAS_DICT, LINKED>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane,
                                              out_len);
     if (lane == 0) {
       a.out_len[b] = out_len;
@@ -516,10 +530,12 @@ extern "C" void lz4mi_debug_enc_phases(unsigned long long *out, int reset) {
 
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
                         uint32_t grid, hipStream_t s) {
-  if (a.dict_len)
-    hipLaunchKernelGGL((encode_fast_kernel<true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  if (a.linked)
+    hipLaunchKernelGGL((encode_fast_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (a.dict_len)
+    hipLaunchKernelGGL((encode_fast_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
   else
-    hipLaunchKernelGGL((encode_fast_kernel<false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
 }
 
 }  // namespace lz4mi

@@ -370,7 +370,7 @@ struct HcScratch {
   uint64_t stride;     // positions per slot
 };
 
-template <bool HAS_DICT>
+template <bool HAS_DICT, bool LINKED>
 __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t max_depth, HcScratch sc,
                                                         uint32_t *counter) {
   const uint32_t lane = lane_id();
@@ -387,6 +387,10 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t ma
     const uint32_t b = next_block(counter, lane);
     if (b >= a.nblocks) break;
     in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    if (LINKED) {  // lz4_frame_encoder.dart:176-180; the encoder keeps the last 65535 bytes (:62-72)
+      in.dict = b == 0 ? a.dict : in.src - 65535;
+      in.D = b == 0 ? a.dict_len : 65535u;
+    }
     in.total = in.D + uni(block_src_len(a, b));
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
@@ -412,7 +416,7 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   // index capacity: dictionary plus the largest block this batch can contain
   uint64_t max_len = a.src_len ? (a.dst_cap_uniform ? a.dst_cap_uniform : (4u << 20)) : a.src_len_uniform;
   if (max_len > kPosMask) max_len = kPosMask;
-  const uint64_t stride = round_up(max_len + a.dict_len + 64, 64);
+  const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
   const uint64_t budget = 8ull << 30;  // bytes of index scratch
   uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);
   while (slots > 4 && (uint64_t)slots * stride * 8 > budget) slots -= 4;
@@ -434,10 +438,12 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   uint32_t grid = (a.nblocks + 3) / 4;
   if (grid > slots / 4) grid = slots / 4;
   uint32_t d32 = depth > 0x7fffffff ? 0x7fffffffu : (uint32_t)depth;
-  if (a.dict_len)
-    hipLaunchKernelGGL((encode_hc_kernel<true>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+  if (a.linked)
+    hipLaunchKernelGGL((encode_hc_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+  else if (a.dict_len)
+    hipLaunchKernelGGL((encode_hc_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
   else
-    hipLaunchKernelGGL((encode_hc_kernel<false>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+    hipLaunchKernelGGL((encode_hc_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
 }

@@ -24,6 +24,9 @@ struct BatchArgs {
   uint32_t nblocks;
   uint32_t *out_len;
   int32_t *status;
+  // Linked blocks (lz4_frame_encoder.dart:170-206): blocks are contiguous (src_stride == src_len_uniform)
+  // and block b >= 1 takes the 65535 bytes in front of it as its dictionary; block 0 takes `dict`.
+  uint32_t linked = 0;
 };
 
 __host__ __device__ inline uint32_t block_src_len(const BatchArgs &a, uint32_t b) {

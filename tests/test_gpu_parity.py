@@ -559,3 +559,32 @@ def test_hc_encoder_chain_quirks_fuzz_vs_oracle(lz, oracle):
         for depth in ((1, 3, 64) if idx % 2 else (2, 7, 1000)):
             got = lz.lz4Compress(data, level=Lz4CompressionLevel.hc, hcOptions=Lz4HcOptions(maxSearchDepth=depth))
             assert got == oracle.block_compress_hc(data, max_search_depth=depth), (idx, len(data), depth)
+
+
+# ------------------------------------------------------------------ linked (dependent) block frames: encode
+
+@pytest.mark.parametrize("hc", [False, True])
+def test_linked_frame_encode_bytes_equal_oracle(lz, oracle, hc):
+    """blockIndependence=false (lz4_frame_encoder.dart:170-206): block 0 uses the external
+    dictionary, every later block the 64 KiB in front of it.  Bytes must equal the oracle's, with
+    and without a dictionary, for a block-aligned and a ragged length, and decode back."""
+    from lz4_amd import Lz4FrameBlockSize, Lz4FrameCompression, Lz4FrameOptions, Lz4HcOptions
+    base = corpus(7, first=1).tobytes()          # ramp, run, text, text, lz, lz, splice
+    rep = (corpus_block(3).tobytes()[:30000]) * 9  # text repeated across block borders: matches into the history
+    d = corpus_block(4).tobytes()[:20000]
+    for data in (base, rep[:200001], base[:65536 * 2 + 777]):
+        for dictionary in (None, d):
+            for bs_id, bs in ((4, Lz4FrameBlockSize.k64KB), (5, Lz4FrameBlockSize.k256KB)):
+                if hc and bs_id == 5 and dictionary is None:
+                    continue  # keep the CPU oracle's HC time down
+                opts = Lz4FrameOptions(blockSize=bs, blockIndependence=False, blockChecksum=True,
+                                       dictId=77 if dictionary else None,
+                                       compression=Lz4FrameCompression.hc if hc else Lz4FrameCompression.fast,
+                                       hcOptions=Lz4HcOptions(maxSearchDepth=16))
+                ref = oracle.frame_encode(data, oracle.frame_options(
+                    block_size_id=bs_id, block_independence=False, block_checksum=True,
+                    dict_id=77 if dictionary else None, compression=1 if hc else 0, hc_max_search_depth=16),
+                    dictionary=dictionary)
+                got = lz.lz4FrameEncodeWithOptions(data, options=opts, dictionary=dictionary)
+                assert got == ref, (len(data), dictionary is not None, bs_id)
+                assert lz.lz4FrameDecode(got, dictionaryResolver=(lambda i: d) if dictionary else None) == data
