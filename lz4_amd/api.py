@@ -43,7 +43,7 @@ def lz4Compress(src, *, level: Lz4CompressionLevel = Lz4CompressionLevel.fast, a
                                        C.byref(out))
     if st:
         N.raise_status(st, ctx.handle)
-    return dst.raw[: out.value]
+    return C.string_at(dst, out.value)
 
 
 def lz4Decompress(src, *, decompressedSize: int, device=None) -> bytes:  # noqa: N802,N803
@@ -56,7 +56,7 @@ def lz4Decompress(src, *, decompressedSize: int, device=None) -> bytes:  # noqa:
     st = N.load().lz4mi_block_decompress(ctx.handle, src, len(src), dst, decompressedSize)
     if st:
         N.raise_status(st, ctx.handle)
-    return dst.raw[:decompressedSize]
+    return C.string_at(dst, decompressedSize)
 
 
 def lz4BlockDecompressInto(src, prefix: bytes = b"", maxLength: int | None = None, device=None) -> bytes:  # noqa: N802,N803
@@ -73,7 +73,7 @@ def lz4BlockDecompressInto(src, prefix: bytes = b"", maxLength: int | None = Non
     st = N.load().lz4mi_block_decompress_into(ctx.handle, src, len(src), buf, len(prefix), maxLength, C.byref(out))
     if st:
         N.raise_status(st, ctx.handle)
-    return buf.raw[: out.value]
+    return C.string_at(buf, out.value)
 
 
 def xxh32(data, seed: int = 0, device=None) -> int:
@@ -117,7 +117,7 @@ def lz4FrameEncodeWithOptions(src, *, options: Lz4FrameOptions, dictionary=None,
     st = L.lz4mi_frame_encode(ctx.handle, src, len(src), C.byref(o), d, len(d) if d else 0, dst, cap, C.byref(out))
     if st:
         N.raise_status(st, ctx.handle)
-    return dst.raw[: out.value]
+    return C.string_at(dst, out.value)  # one copy of the frame, not of the whole bound
 
 
 def lz4FrameEncode(src, *, acceleration: int = 1, dictionary=None, device=None) -> bytes:  # noqa: N802
@@ -135,15 +135,15 @@ def lz4FrameDecode(src, *, maxOutputBytes: int | None = None,  # noqa: N802,N803
     src = bytes(src)
     ctx = _ctx(device)
     L = N.load()
-    base = C.create_string_buffer(src, max(len(src), 1))
-    addr = C.addressof(base)
-    out = bytearray()
+    addr = C.cast(C.c_char_p(src), C.c_void_p).value or 0  # the bytes object itself, no copy
+    parts: list[bytes] = []
+    produced_total = 0
     pos = 0
     dict_bytes: bytes | None = None  # _dict, never cleared between frames (:34,235)
     while pos < len(src):
         bound = C.c_size_t(0)
         L.lz4mi_frame_decode_bound(C.c_void_p(addr + pos), len(src) - pos, C.byref(bound))
-        remaining = -1 if maxOutputBytes is None else maxOutputBytes - len(out)
+        remaining = -1 if maxOutputBytes is None else maxOutputBytes - produced_total
         cap = bound.value if remaining < 0 else min(bound.value, remaining + 1)
         dst = C.create_string_buffer(max(cap, 1))
         consumed, produced, need = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
@@ -170,9 +170,10 @@ def lz4FrameDecode(src, *, maxOutputBytes: int | None = None,  # noqa: N802,N803
             N.raise_status(st, ctx.handle, dict_id=need.value)
         if state == 1:
             dict_bytes = frame_dict
-        out += dst.raw[: produced.value]
+        parts.append(C.string_at(dst, produced.value))
+        produced_total += produced.value
         pos += consumed.value
-    return bytes(out)
+    return parts[0] if len(parts) == 1 else b"".join(parts)
 
 
 __all__ = [
