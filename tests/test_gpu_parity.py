@@ -254,6 +254,46 @@ def test_encoder_ragged_last_block_and_sizes(codec, oracle):
             assert h_slots[b, : int(h_sizes[b])].tobytes() == ref, (block, b)
 
 
+def _structured(rng, n):
+    """Random bytes over a small alphabet with copies spliced in at all distances: short and long
+    literal runs, matches that touch the block end, overlapping (run-length) copies."""
+    a = rng.integers(0, int(rng.choice([2, 4, 16, 256])), size=n, dtype=np.uint8)
+    for _ in range(int(rng.integers(0, 60))):
+        ln = int(rng.integers(4, 600)); s0 = int(rng.integers(0, n)); d0 = int(rng.integers(0, n))
+        ln = min(ln, n - s0, n - d0)
+        a[d0:d0 + ln] = a[s0:s0 + ln].copy()
+    if rng.integers(0, 3) == 0:  # period-k tail (matches running into the end of the block)
+        k = int(rng.integers(1, 40)); t = int(rng.integers(1, min(n, 3000)))
+        a[n - t:] = np.resize(a[:k], t)
+    return a
+
+
+def test_encoder_structured_fuzz_vs_oracle(codec, oracle):
+    """Many blocks of structured random data at several block sizes, accelerations and with a
+    shared dictionary: bytes identical to the oracle, then the decoder gives the source back."""
+    import torch
+    rng = np.random.default_rng(20261112)
+    dict_np = _structured(rng, 40000)
+    for block, nb, accel, use_dict in ((65536, 40, 1, False), (65536, 24, 2, True), (20000, 48, 1, False),
+                                       (4096, 96, 7, True), (777, 128, 1, False), (65536, 16, 40, False)):
+        data = np.concatenate([_structured(rng, block) for _ in range(nb)])
+        data = data[: data.size - int(rng.integers(0, block - 1))]  # ragged last block
+        src = torch.tensor(data, device="cuda")
+        d_t = torch.tensor(dict_np, device="cuda") if use_dict else None
+        slots, sizes, status = codec.compress_blocks(src, block, acceleration=accel, dictionary=d_t)
+        assert int(status.abs().sum()) == 0
+        h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+        for b in range(h_sizes.size):
+            ref = oracle.block_compress_fast(data[b * block:(b + 1) * block].tobytes(), acceleration=accel,
+                                             dictionary=dict_np.tobytes() if use_dict else None)
+            assert h_slots[b, : int(h_sizes[b])].tobytes() == ref, (block, b, accel, use_dict)
+        if not use_dict:
+            out, out_len, st = codec.decompress_blocks(slots, sizes, block, strict=False)
+            assert int(st.abs().sum()) == 0
+            got = np.concatenate([out.cpu().numpy()[b, : int(out_len[b])] for b in range(h_sizes.size)])
+            assert np.array_equal(got, data)
+
+
 def test_encoder_with_dictionary_vs_oracle(lz, oracle):
     text = corpus_block(3).tobytes()
     d32k = text[:32768]
