@@ -46,7 +46,11 @@ __device__ unsigned long long g_enc_phase[PH_SLOTS];
 #endif
 constexpr uint32_t kWinBytes = LZ4MI_WIN, kWinMask = kWinBytes - 1, kSeg = 1024, kWinPad = 16;
 constexpr uint32_t kClaimSlots = 256;  // LDS dwords per wavefront for the same-bucket vote of the re-hash
-constexpr uint32_t kLead = 640;  // an iteration may read ring bytes up to anchor + kLead
+#ifndef LZ4MI_FIRST
+#define LZ4MI_FIRST 8
+#endif
+constexpr uint32_t kFirst = LZ4MI_FIRST;  // probes of a run evaluated in the first step (16 was measured slower: twice the table gather for the ~20 % of runs that need it)
+constexpr uint32_t kLead = kFirst > 8 ? 1024 : 640;  // an iteration may read ring bytes up to anchor + kLead
 
 struct __attribute__((packed)) P32 { uint32_t v; };
 struct __attribute__((packed)) P64 { uint64_t v; };
@@ -174,6 +178,18 @@ __device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_
   }
 }
 
+// smallest h ^ h(lane - k) over k = 1..K within a row of 16 lanes: zero iff an earlier lane holds the same value
+template <int K>
+__device__ __forceinline__ uint32_t shr_min(uint32_t h) {
+  if constexpr (K == 0) {
+    return ~0u;
+  } else {
+    const uint32_t x = h ^ row_shr<K>(h, ~0u);
+    const uint32_t r = shr_min<K - 1>(h);
+    return x < r ? x : r;
+  }
+}
+
 template <bool HAS_DICT, bool LINKED>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
@@ -211,9 +227,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       if (pend) pv = seg_load(w, w.hi, lane);
       PH(0); PH_CNT(8);
 
-      // ---- first 8 probes of the run (:95-103): bytes from the ring
+      // ---- first kFirst probes of the run (:95-103): bytes from the ring
       uint32_t ik = anchor + offA;
-      bool valid = lane < 8 && ik + 4 <= total;
+      bool valid = lane < kFirst && ik + 4 <= total;
       uint32_t seq = w32(w, ik - D);
       uint32_t h = hash16(seq);
       int32_t ref = -1;
@@ -233,15 +249,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       PH(1);
       {
         // Earlier probes of the run that land in the same bucket act as the table entry (:99-100
-        // in program order).  Equal hashes among 8 probes are rare: detect with row shifts, resolve
+        // in program order).  Equal hashes among the first probes are rare: detect with row shifts, resolve
         // out of line.
-        uint32_t mn = h ^ row_shr<1>(h, ~0u);
-        mn = min(mn, h ^ row_shr<2>(h, ~0u));
-        mn = min(mn, h ^ row_shr<3>(h, ~0u));
-        mn = min(mn, h ^ row_shr<4>(h, ~0u));
-        mn = min(mn, h ^ row_shr<5>(h, ~0u));
-        mn = min(mn, h ^ row_shr<6>(h, ~0u));
-        mn = min(mn, h ^ row_shr<7>(h, ~0u));
+        const uint32_t mn = shr_min<kFirst - 1>(h);
         if (ballot(valid && mn == 0)) {
           for (uint32_t j = 0; j + 1 < nvalid; j++) {  // nearest earlier lane with an equal hash wins
             const uint32_t hj = rdlane(h, j), ij = rdlane(ik, j);
@@ -266,8 +276,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       PH(3);
 
       // ---- the rest of the run, 64 probes at a time
-      if (!hm && nvalid == 8) {
-        if (valid) tbl_max(T + h, gtag | (ik + 1));  // :100, all 8 missed
+      if (!hm && nvalid == kFirst) {
+        if (valid) tbl_max(T + h, gtag | (ik + 1));  // :100, all of them missed
         valid = false;
         uint32_t o_last = 0;
         for (uint32_t chunk = 1;; chunk++) {
@@ -461,13 +471,13 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
   uint32_t gen = uni(sc.slot_gen[slot]);
   for (uint32_t k = lane; k < kClaimSlots; k += kWave) s_claim[wave][k] = 0;
 
-  // probe schedule: offA = off(lane), offB = off(lane + 8)
+  // probe schedule: offA = off(lane), offB = off(lane + kFirst)
   uint32_t offA = 0, offB = 0;
   {
     uint32_t o = 0;
-    for (uint32_t t = 0; t < kWave + 8; t++) {
+    for (uint32_t t = 0; t < kWave + kFirst; t++) {
       if (t == lane) offA = o;
-      if (t == lane + 8) offB = o;
+      if (t == lane + kFirst) offB = o;
       o = sched_next(o, sh);
     }
   }
