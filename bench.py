@@ -111,7 +111,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from lz4_amd.device import DeviceCodec
-    from lz4_amd.sharding import frame_offsets
+    from lz4_amd.sharding import frame_offsets_uniform
     from tools.corpus import corpus
 
     nb = args.blocks
@@ -143,7 +143,7 @@ def main():
                 e1.record(stream)
             if world > 1:  # record sizes of every rank -> absolute frame offsets of this rank's blocks
                 rec = torch.where(sizes < BLOCK, sizes, torch.full_like(sizes, BLOCK)) + 4
-                frame_offsets(rec, 7)
+                frame_offsets_uniform(rec, 7)
             _, out_len, st_d = codec.decompress_blocks(slots, sizes, BLOCK, comp_stride=stride, strict=True, out=out)
             if record:
                 e2.record(stream)

@@ -60,3 +60,20 @@ def frame_offsets(local_sizes: torch.Tensor, header_len: int, group=None):
     mine = starts[first:first + local_sizes.numel()].contiguous()
     body_end = int(ends[-1].item()) if all_sizes.numel() else header_len
     return mine, body_end, all_sizes
+
+
+def frame_offsets_uniform(local_sizes: torch.Tensor, header_len: int, group=None):
+    """frame_offsets for the case where every rank holds the same number of blocks (the weak-scaling
+    layout): one all-gather and one prefix sum, nothing read back to the host.  Returns
+    (offsets of this rank's records [int64 tensor], frame body end [0-d int64 tensor])."""
+    n = local_sizes.numel()
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        all_sizes, rank = local_sizes.to(torch.int64), 0
+    else:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        gathered = torch.empty(world * n, dtype=local_sizes.dtype, device=local_sizes.device)
+        dist.all_gather_into_tensor(gathered, local_sizes.contiguous(), group=group)
+        all_sizes = gathered.to(torch.int64)
+    ends = torch.cumsum(all_sizes, 0) + header_len
+    mine = (ends - all_sizes)[rank * n:(rank + 1) * n]
+    return mine, ends[-1] if all_sizes.numel() else torch.tensor(header_len, dtype=torch.int64)

@@ -46,7 +46,7 @@ def _worker(rank, world, port, uneven, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import lz4ref
-        from lz4_amd.sharding import frame_offsets, shard_range
+        from lz4_amd.sharding import frame_offsets, frame_offsets_uniform, shard_range
         from tools.corpus import corpus
         block = 4096
         n_blocks = 23 if uneven else 24
@@ -56,6 +56,9 @@ def _worker(rank, world, port, uneven, q):
         recs = _records(lz4ref, data[lo * block:hi * block], block, True)
         sizes = torch.tensor([len(r) for r in recs], dtype=torch.int32)
         mine, body_end, all_sizes = frame_offsets(sizes, len(header))
+        if not uneven:  # the sync-free form used by the weak-scaling bench must agree
+            mine_u, end_u = frame_offsets_uniform(sizes, len(header))
+            assert torch.equal(mine_u, mine) and int(end_u) == body_end
         buf = torch.zeros(body_end + 4, dtype=torch.uint8)
         for off, r in zip(mine.tolist(), recs):
             buf[off:off + len(r)] = torch.frombuffer(bytearray(r), dtype=torch.uint8)
