@@ -29,7 +29,9 @@ extern "C" {
  * lib/src/block/lz4_block_decoder.dart:23,34,44,51,62,73,107;
  * lib/src/internal/byte_writer.dart:98,131,146; byte_reader.dart:75,104;
  * lib/src/frame/lz4_frame_decoder.dart:54,71,112,131,177,189,193,222,228,233,
- * 252,264,313,319,396; lib/src/frame/lz4_frame_encoder.dart:270. */
+ * 252,264,313,319,396; lib/src/frame/lz4_frame_encoder.dart:270;
+ * lib/src/frame/lz4_frame_stream_encoder.dart:166,225;
+ * lib/src/frame/lz4_frame_stream_decoder.dart:210,425; lib/src/block/lz4_sized_block.dart:41. */
 enum {
   LZ4MI_OK = 0,
   LZ4MI_FORMAT_EOF = 1,              /* Lz4FormatException 'Unexpected end of input' */
@@ -39,6 +41,8 @@ enum {
   LZ4MI_FORMAT_BLOCK_MAX = 5,        /* 'Invalid block maximum size' */
   LZ4MI_FORMAT_INT_OVERFLOW = 6,     /* 'Integer overflow' */
   LZ4MI_FORMAT_CONTENT_SIZE_ARG = 7, /* 'contentSize does not match src length' */
+  LZ4MI_FORMAT_CONTENT_SIZE_STREAM = 8, /* 'contentSize does not match stream length' (stream encoder) */
+  LZ4MI_FORMAT_SIZE_HEADER = 9,      /* 'Input too short for size header' (lz4DecompressWithSize) */
   LZ4MI_CORRUPT_LITERAL = 10,        /* Lz4CorruptDataException 'Literal length exceeds output size' */
   LZ4MI_CORRUPT_MATCH = 11,          /* 'Match length exceeds output size' */
   LZ4MI_CORRUPT_TRAILING = 12,       /* 'Trailing bytes after end of block' */
@@ -53,12 +57,14 @@ enum {
   LZ4MI_LIMIT = 30,                  /* Lz4OutputLimitException 'Output limit exceeded' */
   LZ4MI_UNSUPPORTED_VERSION = 40,    /* Lz4UnsupportedFeatureException 'Unsupported LZ4 frame version' */
   LZ4MI_UNSUPPORTED_DICT = 41,       /* '... no dictionary resolver provided' */
+  LZ4MI_UNSUPPORTED_CONTENT_SIZE = 42, /* 'Content size exceeds supported integer range' (stream decoder) */
   LZ4MI_DICT_NOT_FOUND = 50,         /* Lz4Exception 'Dictionary not found for ID: <id>' */
   LZ4MI_RANGE = 60,                  /* Dart RangeError (argument validation) */
   /* not reference errors */
   LZ4MI_BACKEND = 70,                /* HIP runtime failure; see lz4mi_last_backend_error */
   LZ4MI_DST_TOO_SMALL = 71,          /* caller's destination buffer cannot hold the result */
   LZ4MI_NEED_DICT = 72,              /* lz4mi_frame_decode_next: call again with the dictionary */
+  LZ4MI_STREAM_NEED_INPUT = 74,      /* lz4mi_frame_decoder_next: nothing more can be decoded from the bytes fed so far */
   LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent blocks through the shard calls, blocks of 16 MiB and more) */
 };
 
@@ -114,6 +120,24 @@ int32_t lz4mi_block_decompress_into(lz4mi_ctx *ctx, const uint8_t *src, size_t c
 
 /* xxh32  lib/src/xxhash/xxh32.dart:166-240 (one-shot, host buffer, computed on the GPU). */
 int32_t lz4mi_xxh32(lz4mi_ctx *ctx, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out);
+
+/* Xxh32 (streaming)  lib/src/xxhash/xxh32.dart:21-164.  Plain data owned by the caller:
+ * v1..v4, the <16 carry bytes and the running length, exactly the reference's fields.
+ * update() runs the whole-stripe rounds (:83-118) on the GPU; the carry bookkeeping
+ * (:58-81,:120-124) and the digest's tail + avalanche over at most 15 carried bytes
+ * (:127-163) are host arithmetic on the struct (an update that completes no stripe does
+ * not touch the device and accepts ctx == NULL). */
+typedef struct {
+  uint32_t seed;
+  uint32_t v[4];
+  uint32_t mem_size;
+  uint64_t total_len;
+  uint8_t mem[16];
+} lz4mi_xxh32_state;
+
+void lz4mi_xxh32_state_init(lz4mi_xxh32_state *s, uint32_t seed);
+int32_t lz4mi_xxh32_state_update(lz4mi_ctx *ctx, lz4mi_xxh32_state *s, const uint8_t *data, size_t len);
+uint32_t lz4mi_xxh32_state_digest(const lz4mi_xxh32_state *s);
 
 /* ------------------------------------------------ batches, device-resident
  * The per-block loop bodies of the frame encoder/decoder
@@ -250,6 +274,90 @@ int32_t lz4mi_frame_decode_next(lz4mi_ctx *ctx, const uint8_t *src, size_t len, 
  * parses only the header and walks the block size words on the host.
  * Returns an upper bound (blocks * blockMaxSize), or the contentSize field. */
 int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound);
+
+/* ---------------------------------------------------- host-only frame formats
+ * lz4FrameInfo  lib/src/frame/lz4_frame_info.dart:89-199: magic + descriptor only, no
+ * payload is touched (no GPU work).  Fields mirror Lz4FrameInfo (:13-63); the has_* flags
+ * stand for Dart's nullable fields. */
+typedef struct {
+  uint32_t magic;
+  int32_t is_skippable;
+  int32_t is_legacy;
+  int32_t block_independence; /* 1 unless a standard frame says otherwise (:56) */
+  int32_t block_checksum;
+  int32_t content_checksum;
+  int32_t has_content_size;
+  int32_t has_dict_id;
+  uint32_t skippable_size;    /* valid when is_skippable */
+  uint32_t dict_id;
+  uint32_t block_max_size;    /* 0 for skippable and legacy frames */
+  uint32_t header_size;       /* 8 skippable, 4 legacy, magic..HC otherwise */
+  uint64_t content_size;
+} lz4mi_frame_info;
+
+int32_t lz4mi_frame_info_parse(const uint8_t *src, size_t len, lz4mi_frame_info *out);
+
+/* lz4SkippableFrameEncode  lib/src/frame/lz4_frame_encoder.dart:27-46.
+ * index outside 0..15 or n > 2^32-1 -> LZ4MI_RANGE.  Output is 8 + n bytes. */
+int32_t lz4mi_skippable_frame_encode(const uint8_t *data, size_t n, int32_t index, uint8_t *dst,
+                                     size_t cap, size_t *out_len);
+
+/* lz4LegacyFrameEncode  lib/src/frame/lz4_frame_encoder.dart:55-89: magic 0x184C2102, 8 MiB
+ * blocks, each always stored compressed.  All blocks of the input are encoded in one launch
+ * (one wavefront per block).  An empty input yields the bare magic without looking at
+ * acceleration, as the reference does. */
+size_t lz4mi_legacy_frame_bound(size_t n);
+int32_t lz4mi_legacy_frame_encode(lz4mi_ctx *ctx, const uint8_t *src, size_t n, int64_t acceleration,
+                                  uint8_t *dst, size_t cap, size_t *out_len);
+
+/* ------------------------------------------------------------ stream encoder
+ * lz4FrameEncoderTransformerWithOptions  lib/src/frame/lz4_frame_stream_encoder.dart:25-236.
+ * The transformer's Dart side keeps only the chunk loop: it yields lz4mi_frame_header()'s
+ * bytes first (:42-47), then whatever each update()/finish() call returns.  The buffered
+ * input and the 64 KiB history of linked blocks stay in device memory; one update encodes
+ * every block the chunk completes in a single launch.
+ *
+ * create: options are validated like Lz4FrameOptions (LZ4MI_RANGE).  On any other failure
+ * *out is still set and must be destroyed.
+ * update: a chunk that pushes the total past options.contentSize fails with
+ * LZ4MI_FORMAT_CONTENT_SIZE_STREAM before anything is buffered (:165-167).
+ * finish: last short block, then the contentSize check (:224-226; on that failure *out_len
+ * bytes of dst hold the block that was yielded before the throw), end mark and content
+ * checksum.  dst capacity for either call: lz4mi_frame_encoder_bound(e, n). */
+typedef struct lz4mi_frame_encoder lz4mi_frame_encoder;
+int32_t lz4mi_frame_encoder_create(lz4mi_ctx *ctx, const lz4mi_frame_options *o, const uint8_t *dict,
+                                   size_t dict_len, lz4mi_frame_encoder **out);
+size_t lz4mi_frame_encoder_bound(const lz4mi_frame_encoder *e, size_t n);
+int32_t lz4mi_frame_encoder_update(lz4mi_frame_encoder *e, const uint8_t *chunk, size_t n,
+                                   uint8_t *dst, size_t cap, size_t *out_len);
+int32_t lz4mi_frame_encoder_finish(lz4mi_frame_encoder *e, uint8_t *dst, size_t cap, size_t *out_len);
+void lz4mi_frame_encoder_destroy(lz4mi_frame_encoder *e);
+
+/* ------------------------------------------------------------ stream decoder
+ * _Lz4FrameStreamDecoder behind lz4FrameDecoderTransformer
+ * lib/src/frame/lz4_frame_stream_decoder.dart:15-45 (driver loop), :62-599 (state machine).
+ *
+ *   feed(chunk)            = decoder.add(chunk)                         (:109-111)
+ *   next(dst, cap, ...)    = decoder.decodeNext()                       (:113-413)
+ *   finish()               = decoder.finish()                           (:415-426)
+ *
+ * next returns LZ4MI_OK with *out_len > 0 bytes of output (every complete block buffered so
+ * far that fits into cap, decoded in one launch), LZ4MI_STREAM_NEED_INPUT where decodeNext
+ * returns null, LZ4MI_NEED_DICT when a frame names a dictionary (*dict_id_needed; answer with
+ * lz4mi_frame_decoder_set_dictionary: 1 resolved, 2 no resolver supplied, 3 resolver
+ * returned null, then call next again), LZ4MI_DST_TOO_SMALL with *out_len = the capacity one
+ * step needs (nothing consumed; call again with a larger dst), or the failure.  Output that
+ * precedes a failing block is delivered first; the failure is returned by the call after.
+ * max_output_bytes < 0: no limit (maxOutputBytes: null). */
+typedef struct lz4mi_frame_decoder lz4mi_frame_decoder;
+int32_t lz4mi_frame_decoder_create(lz4mi_ctx *ctx, int64_t max_output_bytes, lz4mi_frame_decoder **out);
+int32_t lz4mi_frame_decoder_feed(lz4mi_frame_decoder *d, const uint8_t *chunk, size_t n);
+int32_t lz4mi_frame_decoder_next(lz4mi_frame_decoder *d, uint8_t *dst, size_t cap, size_t *out_len,
+                                 uint32_t *dict_id_needed);
+int32_t lz4mi_frame_decoder_set_dictionary(lz4mi_frame_decoder *d, const uint8_t *dict, size_t n,
+                                           int32_t answer);
+int32_t lz4mi_frame_decoder_finish(lz4mi_frame_decoder *d);
+void lz4mi_frame_decoder_destroy(lz4mi_frame_decoder *d);
 
 #ifdef __cplusplus
 }

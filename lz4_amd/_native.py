@@ -23,6 +23,9 @@ BACKEND = 70
 DST_TOO_SMALL = 71
 NEED_DICT = 72
 UNSUPPORTED_HERE = 73
+STREAM_NEED_INPUT = 74
+FORMAT_CONTENT_SIZE_STREAM = 8
+FORMAT_SIZE_HEADER = 9
 
 
 class Batch(C.Structure):
@@ -45,6 +48,23 @@ class FrameOptions(C.Structure):
     ]
 
 
+class XxhState(C.Structure):
+    _fields_ = [
+        ("seed", C.c_uint32), ("v", C.c_uint32 * 4), ("mem_size", C.c_uint32), ("total_len", C.c_uint64),
+        ("mem", C.c_uint8 * 16),
+    ]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [
+        ("magic", C.c_uint32), ("is_skippable", C.c_int32), ("is_legacy", C.c_int32),
+        ("block_independence", C.c_int32), ("block_checksum", C.c_int32), ("content_checksum", C.c_int32),
+        ("has_content_size", C.c_int32), ("has_dict_id", C.c_int32), ("skippable_size", C.c_uint32),
+        ("dict_id", C.c_uint32), ("block_max_size", C.c_uint32), ("header_size", C.c_uint32),
+        ("content_size", C.c_uint64),
+    ]
+
+
 # every symbol include/lz4mi.h declares
 EXPORTS = [
     "lz4mi_status_type", "lz4mi_status_message", "lz4mi_ctx_create", "lz4mi_ctx_destroy",
@@ -54,6 +74,12 @@ EXPORTS = [
     "lz4mi_decompress_batch", "lz4mi_xxh32_batch", "lz4mi_xxh32_device", "lz4mi_frame_options_default",
     "lz4mi_frame_bound", "lz4mi_frame_encode", "lz4mi_frame_encode_device", "lz4mi_frame_shard_compress",
     "lz4mi_frame_shard_write", "lz4mi_frame_header", "lz4mi_frame_decode_next", "lz4mi_frame_decode_bound",
+    "lz4mi_xxh32_state_init", "lz4mi_xxh32_state_update", "lz4mi_xxh32_state_digest",
+    "lz4mi_frame_info_parse", "lz4mi_skippable_frame_encode", "lz4mi_legacy_frame_bound",
+    "lz4mi_legacy_frame_encode", "lz4mi_frame_encoder_create", "lz4mi_frame_encoder_bound",
+    "lz4mi_frame_encoder_update", "lz4mi_frame_encoder_finish", "lz4mi_frame_encoder_destroy",
+    "lz4mi_frame_decoder_create", "lz4mi_frame_decoder_feed", "lz4mi_frame_decoder_next",
+    "lz4mi_frame_decoder_set_dictionary", "lz4mi_frame_decoder_finish", "lz4mi_frame_decoder_destroy",
 ]
 
 _lib = None
@@ -114,6 +140,30 @@ def load():
         L.lz4mi_frame_decode_next.argtypes = [vp, vp, sz, psz, u8p, sz, i32, i32, i64, vp, sz, psz,
                                               C.POINTER(u32)]
         L.lz4mi_frame_decode_bound.argtypes = [vp, sz, psz]
+        L.lz4mi_xxh32_state_init.argtypes = [C.POINTER(XxhState), u32]
+        L.lz4mi_xxh32_state_init.restype = None
+        L.lz4mi_xxh32_state_update.argtypes = [vp, C.POINTER(XxhState), u8p, sz]
+        L.lz4mi_xxh32_state_digest.argtypes = [C.POINTER(XxhState)]
+        L.lz4mi_xxh32_state_digest.restype = u32
+        L.lz4mi_frame_info_parse.argtypes = [u8p, sz, C.POINTER(FrameInfo)]
+        L.lz4mi_skippable_frame_encode.argtypes = [u8p, sz, i32, vp, sz, psz]
+        L.lz4mi_legacy_frame_bound.restype = sz
+        L.lz4mi_legacy_frame_bound.argtypes = [sz]
+        L.lz4mi_legacy_frame_encode.argtypes = [vp, u8p, sz, i64, vp, sz, psz]
+        L.lz4mi_frame_encoder_create.argtypes = [vp, C.POINTER(FrameOptions), u8p, sz, C.POINTER(vp)]
+        L.lz4mi_frame_encoder_bound.restype = sz
+        L.lz4mi_frame_encoder_bound.argtypes = [vp, sz]
+        L.lz4mi_frame_encoder_update.argtypes = [vp, u8p, sz, vp, sz, psz]
+        L.lz4mi_frame_encoder_finish.argtypes = [vp, vp, sz, psz]
+        L.lz4mi_frame_encoder_destroy.argtypes = [vp]
+        L.lz4mi_frame_encoder_destroy.restype = None
+        L.lz4mi_frame_decoder_create.argtypes = [vp, i64, C.POINTER(vp)]
+        L.lz4mi_frame_decoder_feed.argtypes = [vp, u8p, sz]
+        L.lz4mi_frame_decoder_next.argtypes = [vp, vp, sz, psz, C.POINTER(u32)]
+        L.lz4mi_frame_decoder_set_dictionary.argtypes = [vp, u8p, sz, i32]
+        L.lz4mi_frame_decoder_finish.argtypes = [vp]
+        L.lz4mi_frame_decoder_destroy.argtypes = [vp]
+        L.lz4mi_frame_decoder_destroy.restype = None
         _lib = L
         return _lib
 

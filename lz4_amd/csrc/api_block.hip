@@ -27,6 +27,8 @@ extern "C" const char *lz4mi_status_message(int32_t s) {
     case LZ4MI_FORMAT_BLOCK_MAX: return "Invalid block maximum size";
     case LZ4MI_FORMAT_INT_OVERFLOW: return "Integer overflow";
     case LZ4MI_FORMAT_CONTENT_SIZE_ARG: return "contentSize does not match src length";
+    case LZ4MI_FORMAT_CONTENT_SIZE_STREAM: return "contentSize does not match stream length";
+    case LZ4MI_FORMAT_SIZE_HEADER: return "Input too short for size header";
     case LZ4MI_CORRUPT_LITERAL: return "Literal length exceeds output size";
     case LZ4MI_CORRUPT_MATCH: return "Match length exceeds output size";
     case LZ4MI_CORRUPT_TRAILING: return "Trailing bytes after end of block";
@@ -41,11 +43,13 @@ extern "C" const char *lz4mi_status_message(int32_t s) {
     case LZ4MI_LIMIT: return "Output limit exceeded";
     case LZ4MI_UNSUPPORTED_VERSION: return "Unsupported LZ4 frame version";
     case LZ4MI_UNSUPPORTED_DICT: return "Dictionary ID present but no dictionary resolver provided";
+    case LZ4MI_UNSUPPORTED_CONTENT_SIZE: return "Content size exceeds supported integer range";
     case LZ4MI_DICT_NOT_FOUND: return "Dictionary not found for ID: ";
     case LZ4MI_RANGE: return "Invalid argument";
     case LZ4MI_BACKEND: return "HIP backend failure";
     case LZ4MI_DST_TOO_SMALL: return "destination buffer too small";
     case LZ4MI_NEED_DICT: return "dictionary required";
+    case LZ4MI_STREAM_NEED_INPUT: return "more input required";
     case LZ4MI_UNSUPPORTED_HERE: return "not supported by the device path";
     default: return "unknown status";
   }

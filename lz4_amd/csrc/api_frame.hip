@@ -3,12 +3,11 @@
 // (lib/src/frame/lz4_frame_encoder.dart:154-261, lz4_frame_decoder.dart:238-304)
 // runs as batched kernels over all blocks of the frame.
 #include "api_common.h"
+#include "frame_host.h"
 
 using namespace lz4mi;
 
-namespace {
-
-const uint32_t kFrameMagic = 0x184D2204u, kSkippableBase = 0x184D2A50u, kLegacyMagic = 0x184C2102u;
+namespace lz4mi {
 
 // xxHash32 of a frame descriptor (2..14 bytes, always < 16 so only the short tail
 // path of lib/src/xxhash/xxh32.dart:215-239 applies).  Host-side because the header is
@@ -28,13 +27,6 @@ uint32_t descriptor_hash(const uint8_t *p, size_t len) {
   h *= 0xC2B2AE3Du;
   h ^= h >> 16;
   return h;
-}
-
-inline uint32_t rd32(const uint8_t *p) {
-  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
-inline void wr32(uint8_t *p, uint32_t v) {
-  p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
 }
 
 int32_t validate_options(const lz4mi_frame_options *o) {
@@ -144,7 +136,27 @@ int32_t shard_write(lz4mi_ctx *c, const uint64_t *d_rec_off, uint8_t *d_dst) {
   return LZ4MI_OK;
 }
 
-}  // namespace
+int32_t encode_records(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4mi_frame_options *o,
+                       const uint8_t *d_dict, uint32_t dict_len, uint8_t *d_dst, uint64_t base, uint64_t *end) {
+  uint32_t nb = 0;
+  int32_t st = shard_compress(c, d_src, n, o, d_dict, dict_len, &nb);
+  if (st) return st;
+  LZ4MI_HIP(c, c->rec_off.ensure((size_t)(nb + 1) * 8));
+  LZ4MI_HIP(c, c->total.ensure(64));
+  st = pin_reserve(c, 256);
+  if (st) return st;
+  launch_scan_sizes(c->record_size.as<uint32_t>(), nb, base, c->rec_off.as<uint64_t>(), c->total.as<uint64_t>(),
+                    c->stream);
+  st = shard_write(c, c->rec_off.as<uint64_t>(), d_dst);
+  if (st) return st;
+  uint64_t *h_total = (uint64_t *)((uint8_t *)c->h_pin + 128);
+  LZ4MI_HIP(c, hipMemcpyAsync(h_total, c->total.p, 8, hipMemcpyDeviceToHost, c->stream));
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  *end = *h_total;
+  return LZ4MI_OK;
+}
+
+}  // namespace lz4mi
 
 extern "C" void lz4mi_frame_options_default(lz4mi_frame_options *o) {  // lz4_frame_options.dart:78-88
   memset(o, 0, sizeof *o);
@@ -211,23 +223,13 @@ extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src,
   if (st) return st;
   memcpy(c->h_pin, hdr, hlen);
   LZ4MI_HIP(c, hipMemcpyAsync(d_dst, c->h_pin, hlen, hipMemcpyHostToDevice, c->stream));
-  uint32_t nb = 0;
-  st = shard_compress(c, d_src, n, o, d_dict, dict_len, &nb);
-  if (st) return st;
-  LZ4MI_HIP(c, c->rec_off.ensure((size_t)(nb + 1) * 8));
-  LZ4MI_HIP(c, c->total.ensure(64));
   LZ4MI_HIP(c, c->words.ensure(64));
-  launch_scan_sizes(c->record_size.as<uint32_t>(), nb, hlen, c->rec_off.as<uint64_t>(), c->total.as<uint64_t>(),
-                    c->stream);
-  st = shard_write(c, c->rec_off.as<uint64_t>(), d_dst);
-  if (st) return st;
   if (o->content_checksum)  // Xxh32 over all uncompressed content (:148,163,266)
     launch_xxh32_serial(d_src, n, 0, c->words.as<uint32_t>(), c->stream);
+  uint64_t body_end = 0;
+  st = encode_records(c, d_src, n, o, d_dict, dict_len, d_dst, hlen, &body_end);
+  if (st) return st;
   // end mark (:263) [+ content checksum] behind the last record
-  uint64_t *h_total = (uint64_t *)((uint8_t *)c->h_pin + 128);
-  LZ4MI_HIP(c, hipMemcpyAsync(h_total, c->total.p, 8, hipMemcpyDeviceToHost, c->stream));
-  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-  const uint64_t body_end = *h_total;
   launch_put_words(d_dst + body_end, c->words.as<uint32_t>(), o->content_checksum ? 1 : 0, true, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   if (out_len) *out_len = body_end + 4 + (o->content_checksum ? 4 : 0);
@@ -269,23 +271,7 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
 
 // --------------------------------------------------------------- frame decode
 
-namespace {
-
-struct Blk {
-  uint64_t payload_off;  // relative to the frame's first byte handed to the device
-  uint32_t size;
-  uint32_t raw;
-  uint32_t has_ck;
-  uint32_t ck;
-};
-
-struct Header {
-  int indep, block_ck, has_size, content_ck, has_dict;
-  size_t bmax;
-  uint64_t content_size;
-  uint32_t dict_id;
-  size_t len;  // bytes after the magic, including HC
-};
+namespace lz4mi {
 
 // Header parse + validation in the reference's order (lz4_frame_decoder.dart:166-223).
 int32_t parse_header(const uint8_t *p, size_t rem, Header *h) {
@@ -328,7 +314,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
                       size_t slot, bool indep, const uint8_t *dict, size_t dict_len, bool have_dict,
                       int32_t walk_err, int64_t max_out, bool want_content_hash, bool legacy,
                       bool legacy_last_has_next, uint8_t *dst,
-                      size_t cap, size_t *out_len, uint32_t *content_hash) {
+                      size_t cap, size_t *out_len, uint32_t *content_hash, DecodeExtras *extras) {
   const uint32_t nb = (uint32_t)blocks.size();
   *out_len = 0;
   if (nb == 0) {
@@ -479,7 +465,15 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     }
   }
   if (!err && walk_err) err = walk_err;
+  if (err && extras && extras->partial) {  // deliver the blocks in front of the failing one
+    extras->deferred = err;
+    err = LZ4MI_OK;
+  }
   if (err) return err;
+  if (extras) {
+    extras->good_blocks = good;
+    extras->sizes.assign(h_olen, h_olen + good);
+  }
 
   // gather the output
   const uint8_t *d_frame_out = c->out.as<uint8_t>();
@@ -511,11 +505,12 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   if (produced) LZ4MI_HIP(c, hipMemcpyAsync(dst, d_frame_out, produced, hipMemcpyDeviceToHost, c->stream));
   LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
   if (want_content_hash) *content_hash = *(uint32_t *)((uint8_t *)c->h_pin + hb);
+  if (extras) extras->d_out = d_frame_out;
   *out_len = produced;
   return LZ4MI_OK;
 }
 
-}  // namespace
+}  // namespace lz4mi
 
 extern "C" int32_t lz4mi_frame_decode_next(lz4mi_ctx *c, const uint8_t *src, size_t len, size_t *consumed,
                                            const uint8_t *dict, size_t dict_len, int32_t dict_state,

@@ -70,5 +70,6 @@ void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeSc
 void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_table, hipStream_t s);
 void launch_xxh32_batch(const BatchArgs &a, uint32_t *d_hash, hipStream_t s);
 void launch_xxh32_serial(const uint8_t *d_data, uint64_t len, uint32_t seed, uint32_t *d_out, hipStream_t s);
+void launch_xxh32_stripes(const uint8_t *d_data, uint64_t stripes, uint32_t *d_state, hipStream_t s);
 
 }  // namespace lz4mi

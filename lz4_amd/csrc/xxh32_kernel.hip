@@ -92,6 +92,43 @@ __global__ __launch_bounds__(256) void xxh32_batch_kernel(BatchArgs a, uint32_t 
 // while the current one is hashed), pre-multiply every word by PRIME32_2 and park the products in
 // LDS; lanes 0-3 then only do  v = rotl(v + y, 13) * PRIME32_1  with y read from LDS.
 constexpr uint32_t kXChunk = 4096;  // bytes per step: 64 lanes x 4 x 16
+
+// Runs `stripes` 16-byte stripes of one stream through the four accumulators; lanes 0-3 pass in
+// and get back v1..v4 (acc = lane & 3), the other lanes only fetch.
+__device__ __forceinline__ uint32_t xxh_stream_rounds(uint32_t v, const uint8_t *data, uint64_t stripes,
+                                                      uint32_t *s_y, uint32_t lane, uint32_t acc) {
+  const uint64_t chunks = stripes / (kXChunk / 16);
+  U128U nx[4];
+  if (chunks) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) nx[k] = ld128(data + 1024 * k + 16 * lane);
+  }
+  for (uint64_t c = 0; c < chunks; c++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {  // word w of the chunk sits at s_y[w]
+      const u32x4 y = {nx[k].a * XP2, nx[k].b * XP2, nx[k].c * XP2, nx[k].d * XP2};
+      *(lds_u128 *)((lds_u8 *)s_y + 1024 * k + 16 * lane) = y;
+    }
+    if (c + 1 < chunks) {
+      const uint8_t *q = data + (c + 1) * kXChunk;
+#pragma unroll
+      for (int k = 0; k < 4; k++) nx[k] = ld128(q + 1024 * k + 16 * lane);
+    }
+    if (lane < 4) {
+      const lds_u32 *yy = (const lds_u32 *)s_y + acc;
+      for (uint32_t st = 0; st < kXChunk / 16; st += 16) {
+        uint32_t y[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) y[u] = yy[(st + u) * 4];
+#pragma unroll
+        for (int u = 0; u < 16; u++) v = rotl32(v + y[u], 13) * XP1;
+      }
+    }
+  }
+  if (lane < 4) v = xxh_consume(v, data + chunks * kXChunk, stripes - chunks * (kXChunk / 16), acc);
+  return v;
+}
+
 __global__ __launch_bounds__(64) void xxh32_serial_kernel(const uint8_t *data, uint64_t len, uint32_t seed,
                                                           uint32_t *out) {
   __shared__ __attribute__((aligned(16))) uint32_t s_y[kXChunk / 4];
@@ -99,37 +136,7 @@ __global__ __launch_bounds__(64) void xxh32_serial_kernel(const uint8_t *data, u
   const uint32_t acc = lane & 3;
   uint32_t h;
   if (len >= 16) {
-    uint32_t v = xxh_init_acc(acc, seed);
-    const uint64_t stripes = len / 16;
-    const uint64_t chunks = stripes / (kXChunk / 16);
-    U128U nx[4];
-    if (chunks) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) nx[k] = ld128(data + 1024 * k + 16 * lane);
-    }
-    for (uint64_t c = 0; c < chunks; c++) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {  // word w of the chunk sits at s_y[w]
-        const u32x4 y = {nx[k].a * XP2, nx[k].b * XP2, nx[k].c * XP2, nx[k].d * XP2};
-        *(lds_u128 *)((lds_u8 *)s_y + 1024 * k + 16 * lane) = y;
-      }
-      if (c + 1 < chunks) {
-        const uint8_t *q = data + (c + 1) * kXChunk;
-#pragma unroll
-        for (int k = 0; k < 4; k++) nx[k] = ld128(q + 1024 * k + 16 * lane);
-      }
-      if (lane < 4) {
-        const lds_u32 *yy = (const lds_u32 *)s_y + acc;
-        for (uint32_t st = 0; st < kXChunk / 16; st += 16) {
-          uint32_t y[16];
-#pragma unroll
-          for (int u = 0; u < 16; u++) y[u] = yy[(st + u) * 4];
-#pragma unroll
-          for (int u = 0; u < 16; u++) v = rotl32(v + y[u], 13) * XP1;
-        }
-      }
-    }
-    if (lane < 4) v = xxh_consume(v, data + chunks * kXChunk, stripes - chunks * (kXChunk / 16), acc);
+    uint32_t v = xxh_stream_rounds(xxh_init_acc(acc, seed), data, len / 16, s_y, lane, acc);
     h = xxh_merge4(lane < 4 ? v : 0u, acc, lane);
   } else {
     h = seed + XP5;
@@ -141,6 +148,16 @@ __global__ __launch_bounds__(64) void xxh32_serial_kernel(const uint8_t *data, u
   }
 }
 
+// Streaming form (Xxh32.update, lib/src/xxhash/xxh32.dart:83-118): advances v1..v4 in `state`
+// over whole stripes; carry bytes and the digest stay with the caller.
+__global__ __launch_bounds__(64) void xxh32_stripes_kernel(const uint8_t *data, uint64_t stripes, uint32_t *state) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_y[kXChunk / 4];
+  const uint32_t lane = lane_id();
+  const uint32_t acc = lane & 3;
+  uint32_t v = xxh_stream_rounds(state[acc], data, stripes, s_y, lane, acc);
+  if (lane < 4) state[acc] = v;
+}
+
 void launch_xxh32_batch(const BatchArgs &a, uint32_t *d_hash, hipStream_t s) {
   if (a.nblocks == 0) return;
   uint32_t waves = (a.nblocks + 15) / 16;
@@ -149,6 +166,10 @@ void launch_xxh32_batch(const BatchArgs &a, uint32_t *d_hash, hipStream_t s) {
 
 void launch_xxh32_serial(const uint8_t *d_data, uint64_t len, uint32_t seed, uint32_t *d_out, hipStream_t s) {
   hipLaunchKernelGGL(xxh32_serial_kernel, dim3(1), dim3(64), 0, s, d_data, len, seed, d_out);
+}
+
+void launch_xxh32_stripes(const uint8_t *d_data, uint64_t stripes, uint32_t *d_state, hipStream_t s) {
+  hipLaunchKernelGGL(xxh32_stripes_kernel, dim3(1), dim3(64), 0, s, d_data, stripes, d_state);
 }
 
 }  // namespace lz4mi

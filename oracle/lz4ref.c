@@ -32,6 +32,8 @@ const char *lz4ref_status_message(int s) {
     case LZ4REF_FORMAT_BLOCK_MAX: return "Invalid block maximum size";
     case LZ4REF_FORMAT_INT_OVERFLOW: return "Integer overflow";
     case LZ4REF_FORMAT_CONTENT_SIZE_ARG: return "contentSize does not match src length";
+    case LZ4REF_FORMAT_CONTENT_SIZE_STREAM: return "contentSize does not match stream length";
+    case LZ4REF_FORMAT_SIZE_HEADER: return "Input too short for size header";
     case LZ4REF_CORRUPT_LITERAL: return "Literal length exceeds output size";
     case LZ4REF_CORRUPT_MATCH: return "Match length exceeds output size";
     case LZ4REF_CORRUPT_TRAILING: return "Trailing bytes after end of block";
@@ -47,6 +49,7 @@ const char *lz4ref_status_message(int s) {
     case LZ4REF_UNSUPPORTED_VERSION: return "Unsupported LZ4 frame version";
     case LZ4REF_UNSUPPORTED_DICT:
       return "Dictionary ID present but no dictionary resolver provided";
+    case LZ4REF_UNSUPPORTED_CONTENT_SIZE: return "Content size exceeds supported integer range";
     case LZ4REF_DICT_NOT_FOUND: return "Dictionary not found for ID: ";
     case LZ4REF_RANGE: return "Invalid argument";
     case LZ4REF_DST_TOO_SMALL: return "destination buffer too small";
@@ -911,4 +914,766 @@ int lz4ref_frame_decode(const uint8_t *src, size_t len, int64_t max_output_bytes
   if (out_len) *out_len = d.out.len;
   if (err_dict_id) *err_dict_id = d.err_dict_id;
   return st;
+}
+
+/* ===================================================== host-only frame formats */
+
+static void put32(uint8_t *p, uint32_t v) {
+  p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24);
+}
+
+/* frame/lz4_frame_info.dart:89-199 */
+int lz4ref_frame_info(const uint8_t *src, size_t len, lz4ref_frame_info_t *out) {
+  memset(out, 0, sizeof *out);
+  out->block_independence = 1; /* ctor defaults :56-61 */
+  src_t r = {src, len, 0};
+  if (src_remaining(&r) < 4) return LZ4REF_FORMAT_EOF; /* :92-94 */
+  uint32_t magic;
+  src_u32le(&r, &magic);
+  out->magic = magic;
+  if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) { /* :99-111 */
+    if (src_remaining(&r) < 4) return LZ4REF_FORMAT_EOF;
+    uint32_t size;
+    src_u32le(&r, &size);
+    out->is_skippable = 1;
+    out->skippable_size = size;
+    out->header_size = 8;
+    return LZ4REF_OK;
+  }
+  if (magic == 0x184C2102u) { /* :114-121 */
+    out->is_legacy = 1;
+    out->header_size = 4;
+    return LZ4REF_OK;
+  }
+  if (magic != 0x184D2204u) return LZ4REF_FORMAT_MAGIC; /* :124-126 */
+  size_t desc_start = r.off;
+  if (src_remaining(&r) < 3) return LZ4REF_FORMAT_EOF; /* :130-132 */
+  uint32_t flg = 0, bd = 0;
+  src_u8(&r, &flg);
+  src_u8(&r, &bd);
+  if (((flg >> 6) & 3) != 1) return LZ4REF_UNSUPPORTED_VERSION; /* :137-140 */
+  int indep = (flg >> 5) & 1, block_ck = (flg >> 4) & 1, has_size = (flg >> 3) & 1;
+  int content_ck = (flg >> 2) & 1, has_dict = flg & 1;
+  if ((flg >> 1) & 1) return LZ4REF_FORMAT_FLG_RESERVED; /* :149-151 */
+  if (bd & 0x8F) return LZ4REF_FORMAT_BD_RESERVED;       /* :153-155 */
+  size_t bmax = block_max_bytes((bd >> 4) & 7);
+  if (!bmax) return LZ4REF_FORMAT_BLOCK_MAX; /* :157-158, :201-214 */
+  uint64_t content_size = 0;
+  if (has_size) { /* :160-166 */
+    if (src_remaining(&r) < 8) return LZ4REF_FORMAT_EOF;
+    uint32_t lo, hi;
+    src_u32le(&r, &lo);
+    src_u32le(&r, &hi);
+    content_size = ((uint64_t)hi << 32) | lo;
+    if (content_size >> 63) return LZ4REF_FORMAT_INT_OVERFLOW; /* byte_reader.dart:74-76 */
+  }
+  uint32_t dict_id = 0;
+  if (has_dict) { /* :168-174 */
+    if (src_remaining(&r) < 4) return LZ4REF_FORMAT_EOF;
+    src_u32le(&r, &dict_id);
+  }
+  size_t desc_end = r.off;
+  uint32_t hc;
+  int st = src_u8(&r, &hc); /* :178 */
+  if (st) return st;
+  if (hc != ((lz4ref_xxh32(src + desc_start, desc_end - desc_start, 0) >> 8) & 0xff))
+    return LZ4REF_CORRUPT_HEADER_CK; /* :181-185 */
+  out->block_independence = indep;
+  out->block_checksum = block_ck;
+  out->content_checksum = content_ck;
+  out->has_content_size = has_size;
+  out->content_size = content_size;
+  out->has_dict_id = has_dict;
+  out->dict_id = dict_id;
+  out->block_max_size = (uint32_t)bmax;
+  out->header_size = (uint32_t)r.off;
+  return LZ4REF_OK;
+}
+
+/* frame/lz4_frame_encoder.dart:27-46 */
+int lz4ref_skippable_frame_encode(const uint8_t *data, size_t n, int index, uint8_t *dst, size_t cap,
+                                  size_t *out_len) {
+  if (index < 0 || index > 15) return LZ4REF_RANGE;         /* :28-30 */
+  if ((uint64_t)n > 0xFFFFFFFFull) return LZ4REF_RANGE;     /* :31-33 */
+  sink_t w = {dst, 0, cap, -1};
+  int st;
+  if ((st = sink_u32le(&w, 0x184D2A50u + (uint32_t)index))) return st;
+  if ((st = sink_u32le(&w, (uint32_t)n))) return st;
+  if ((st = sink_put(&w, data, n))) return st;
+  if (out_len) *out_len = w.len;
+  return LZ4REF_OK;
+}
+
+size_t lz4ref_legacy_frame_bound(size_t n) {
+  const size_t bm = 8u * 1024 * 1024;
+  size_t nb = (n + bm - 1) / bm;
+  return 4 + nb * (4 + 16 + bm / 255 + 1) + n;
+}
+
+/* frame/lz4_frame_encoder.dart:55-89 */
+int lz4ref_legacy_frame_encode(const uint8_t *src, size_t n, int64_t acceleration, uint8_t *dst,
+                               size_t cap, size_t *out_len) {
+  const size_t bm = 8u * 1024 * 1024;
+  sink_t w = {dst, 0, cap, -1};
+  int st;
+  if ((st = sink_u32le(&w, 0x184C2102u))) return st; /* :59 */
+  size_t offset = 0;
+  while (offset < n) { /* :62 */
+    size_t end = offset + bm;
+    if (end > n) end = n;
+    size_t size_at = w.len;
+    if ((st = sink_u32le(&w, 0))) return st;
+    size_t start = w.len;
+    /* lz4BlockCompress(chunk, acceleration): no dictionary; both branches of :75-83
+     * write the compressed form */
+    if ((st = fast_encode_to_sink(&w, src + offset, end - offset, NULL, 0, acceleration))) return st;
+    put32(w.buf + size_at, (uint32_t)(w.len - start));
+    offset = end;
+  }
+  if (out_len) *out_len = w.len;
+  return LZ4REF_OK;
+}
+
+/* block/lz4_sized_block.dart:15-31 */
+int lz4ref_compress_with_size(const uint8_t *src, size_t n, int level, int64_t param, uint8_t *dst,
+                              size_t cap, size_t *out_len) {
+  sink_t w = {dst, 0, cap, -1};
+  int st;
+  if ((st = sink_u32le(&w, (uint32_t)n))) return st; /* setUint32 truncates to 32 bits :28 */
+  st = level == 0 ? fast_encode_to_sink(&w, src, n, NULL, 0, param)
+                  : hc_encode_to_sink(&w, src, n, NULL, 0, param);
+  if (st) return st;
+  if (out_len) *out_len = w.len;
+  return LZ4REF_OK;
+}
+
+/* block/lz4_sized_block.dart:39-55 */
+int lz4ref_decompress_with_size(const uint8_t *src, size_t len, uint8_t *dst, size_t cap,
+                                size_t *out_len) {
+  if (len < 4) return LZ4REF_FORMAT_SIZE_HEADER; /* :40-42 */
+  uint32_t size = rd32(src);
+  if (size > cap) return LZ4REF_DST_TOO_SMALL;
+  int st = lz4ref_block_decompress(src + 4, len - 4, dst, (int64_t)size);
+  if (st) return st;
+  if (out_len) *out_len = size;
+  return LZ4REF_OK;
+}
+
+/* ============================================================ stream encoder
+ * frame/lz4_frame_stream_encoder.dart:25-236 */
+struct lz4ref_stream_encoder {
+  lz4ref_frame_options o;
+  size_t bmax;
+  uint8_t *dict;      /* dictionary argument (NULL = null) */
+  size_t dict_len;
+  int have_dict;
+  uint64_t total_in;
+  lz4ref_xxh32_state hasher;
+  uint8_t *buf;       /* BytesBuilder contents */
+  size_t buffered, buf_cap;
+  uint8_t history[64 * 1024];
+  size_t history_len;
+};
+
+lz4ref_stream_encoder *lz4ref_stream_encoder_new(const lz4ref_frame_options *o, const uint8_t *dict,
+                                                 size_t dict_len, int *status) {
+  *status = LZ4REF_OK;
+  if (o->acceleration < 1 || !block_max_bytes(o->block_size_id) ||
+      (o->compression == 1 && o->hc_max_search_depth < 1)) { /* options ctor */
+    *status = LZ4REF_RANGE;
+    return NULL;
+  }
+  lz4ref_stream_encoder *e = (lz4ref_stream_encoder *)calloc(1, sizeof *e);
+  if (!e) { *status = LZ4REF_DST_TOO_SMALL; return NULL; }
+  e->o = *o;
+  e->bmax = block_max_bytes(o->block_size_id);
+  if (dict) {
+    e->have_dict = 1;
+    e->dict = (uint8_t *)malloc(dict_len ? dict_len : 1);
+    memcpy(e->dict, dict, dict_len);
+    e->dict_len = dict_len;
+  }
+  lz4ref_xxh32_init(&e->hasher, 0);
+  const size_t window = 64 * 1024;
+  if (e->have_dict && !o->block_independence) { /* :64-73 */
+    if (dict_len > window) {
+      memcpy(e->history, dict + dict_len - window, window);
+      e->history_len = window;
+    } else {
+      memcpy(e->history, dict, dict_len);
+      e->history_len = dict_len;
+    }
+  }
+  return e;
+}
+
+void lz4ref_stream_encoder_free(lz4ref_stream_encoder *e) {
+  if (!e) return;
+  free(e->dict);
+  free(e->buf);
+  free(e);
+}
+
+/* _encodeHeader :238-266 */
+int lz4ref_stream_encoder_header(lz4ref_stream_encoder *e, uint8_t *dst, size_t cap, size_t *out_len) {
+  const lz4ref_frame_options *o = &e->o;
+  sink_t w = {dst, 0, cap, -1};
+  int st;
+  uint32_t flg = (1u << 6) | ((o->block_independence ? 1u : 0u) << 5) |
+                 ((o->block_checksum ? 1u : 0u) << 4) | ((o->has_content_size ? 1u : 0u) << 3) |
+                 ((o->content_checksum ? 1u : 0u) << 2) | (o->has_dict_id ? 1u : 0u); /* :32-37 */
+  uint32_t bd = ((uint32_t)o->block_size_id & 7u) << 4;
+  if ((st = sink_u32le(&w, 0x184D2204u))) return st;
+  if ((st = sink_u8(&w, flg))) return st;
+  if ((st = sink_u8(&w, bd))) return st;
+  if (o->has_content_size) {
+    if ((st = sink_u32le(&w, (uint32_t)(o->content_size & 0xFFFFFFFFu)))) return st;
+    if ((st = sink_u32le(&w, (uint32_t)(o->content_size >> 32)))) return st;
+  }
+  if (o->has_dict_id && (st = sink_u32le(&w, o->dict_id))) return st;
+  uint32_t hc = (lz4ref_xxh32(w.buf + 4, w.len - 4, 0) >> 8) & 0xff;
+  if ((st = sink_u8(&w, hc))) return st;
+  *out_len = w.len;
+  return LZ4REF_OK;
+}
+
+static void senc_append_history(lz4ref_stream_encoder *e, const uint8_t *bytes, size_t n) { /* :75-96 */
+  const size_t window = 64 * 1024;
+  if (n >= window) {
+    memcpy(e->history, bytes + n - window, window);
+    e->history_len = window;
+    return;
+  }
+  size_t required = e->history_len + n;
+  if (required <= window) {
+    memcpy(e->history + e->history_len, bytes, n);
+    e->history_len = required;
+    return;
+  }
+  size_t drop = required - window;
+  size_t keep = e->history_len - drop;
+  memmove(e->history, e->history + drop, keep);
+  e->history_len = keep;
+  memcpy(e->history + e->history_len, bytes, n);
+  e->history_len += n;
+}
+
+/* encodeBlock :108-156, appended to w as one piece */
+static int senc_encode_block(lz4ref_stream_encoder *e, sink_t *w, const uint8_t *chunk, size_t n) {
+  const lz4ref_frame_options *o = &e->o;
+  const uint8_t *d = NULL;
+  size_t dl = 0;
+  if (o->block_independence) { /* :187-188 */
+    if (e->have_dict) { d = e->dict; dl = e->dict_len; }
+  } else if (e->history_len != 0) { /* :190-192 */
+    d = e->history;
+    dl = e->history_len;
+  }
+  int st;
+  size_t start = w->len;
+  if ((st = sink_u32le(w, 0))) return st;
+  size_t payload = w->len;
+  st = o->compression == 0 ? fast_encode_to_sink(w, chunk, n, d, dl, o->acceleration)
+                           : hc_encode_to_sink(w, chunk, n, d, dl, o->hc_max_search_depth);
+  if (st) return st;
+  size_t clen = w->len - payload;
+  if (clen < n) { /* :136-144 */
+    put32(w->buf + start, (uint32_t)clen);
+    if (o->block_checksum && (st = sink_u32le(w, lz4ref_xxh32(w->buf + payload, clen, 0)))) return st;
+  } else { /* :145-155 */
+    w->len = start;
+    if ((st = sink_u32le(w, 0x80000000u | (uint32_t)n))) return st;
+    if ((st = sink_put(w, chunk, n))) return st;
+    if (o->block_checksum && (st = sink_u32le(w, lz4ref_xxh32(chunk, n, 0)))) return st;
+  }
+  return LZ4REF_OK;
+}
+
+static int piece_done(sink_t *w, size_t *mark, uint32_t *lens, size_t cap, size_t *np) {
+  if (*np >= cap) return LZ4REF_DST_TOO_SMALL;
+  lens[(*np)++] = (uint32_t)(w->len - *mark);
+  *mark = w->len;
+  return LZ4REF_OK;
+}
+
+/* body of `await for (final chunk in input)` :158-201 */
+int lz4ref_stream_encoder_add(lz4ref_stream_encoder *e, const uint8_t *chunk, size_t n, uint8_t *dst,
+                              size_t cap, size_t *out_len, uint32_t *piece_lens, size_t piece_cap,
+                              size_t *npieces) {
+  *out_len = 0;
+  *npieces = 0;
+  if (n == 0) return LZ4REF_OK; /* :160-162 */
+  e->total_in += n;
+  if (e->o.has_content_size && e->total_in > e->o.content_size) /* :165-167 */
+    return LZ4REF_FORMAT_CONTENT_SIZE_STREAM;
+  if (e->o.content_checksum) lz4ref_xxh32_update(&e->hasher, chunk, n); /* :168-170 */
+  if (e->buffered + n > e->buf_cap) { /* buf.add(bytes) :172 */
+    size_t nc = (e->buffered + n) * 2 + 64;
+    e->buf = (uint8_t *)realloc(e->buf, nc);
+    e->buf_cap = nc;
+  }
+  memcpy(e->buf + e->buffered, chunk, n);
+  e->buffered += n;
+  sink_t w = {dst, 0, cap, -1};
+  size_t mark = 0;
+  int st = LZ4REF_OK;
+  size_t taken = 0;
+  while (e->buffered - taken >= e->bmax) { /* :175-200 */
+    const uint8_t *block = e->buf + taken;
+    if ((st = senc_encode_block(e, &w, block, e->bmax))) break;
+    if ((st = piece_done(&w, &mark, piece_lens, piece_cap, npieces))) break;
+    if (!e->o.block_independence) senc_append_history(e, block, e->bmax);
+    taken += e->bmax;
+  }
+  memmove(e->buf, e->buf + taken, e->buffered - taken);
+  e->buffered -= taken;
+  *out_len = mark;
+  return st;
+}
+
+/* after the loop :203-234 */
+int lz4ref_stream_encoder_close(lz4ref_stream_encoder *e, uint8_t *dst, size_t cap, size_t *out_len,
+                                uint32_t *piece_lens, size_t piece_cap, size_t *npieces) {
+  *out_len = 0;
+  *npieces = 0;
+  sink_t w = {dst, 0, cap, -1};
+  size_t mark = 0;
+  int st;
+  if (e->buffered != 0) { /* :203-222 */
+    if ((st = senc_encode_block(e, &w, e->buf, e->buffered))) return st;
+    if ((st = piece_done(&w, &mark, piece_lens, piece_cap, npieces))) return st;
+    if (!e->o.block_independence) senc_append_history(e, e->buf, e->buffered);
+    e->buffered = 0;
+  }
+  *out_len = mark;
+  if (e->o.has_content_size && e->total_in != e->o.content_size) /* :224-226 */
+    return LZ4REF_FORMAT_CONTENT_SIZE_STREAM;
+  if ((st = sink_u32le(&w, 0))) return st; /* :228 */
+  if ((st = piece_done(&w, &mark, piece_lens, piece_cap, npieces))) return st;
+  if (e->o.content_checksum) { /* :230-234 */
+    if ((st = sink_u32le(&w, lz4ref_xxh32_digest(&e->hasher)))) return st;
+    if ((st = piece_done(&w, &mark, piece_lens, piece_cap, npieces))) return st;
+  }
+  *out_len = mark;
+  return LZ4REF_OK;
+}
+
+/* ============================================================ stream decoder
+ * frame/lz4_frame_stream_decoder.dart:62-599 */
+enum {
+  SD_MAGIC, SD_SKIP_SIZE, SD_SKIP_SKIP, SD_DESCRIPTOR, SD_HEADER_CK, SD_BLOCK_SIZE, SD_BLOCK_DATA,
+  SD_BLOCK_CK, SD_CONTENT_CK, SD_LEGACY_SIZE, SD_LEGACY_DATA, SD_LEGACY_AFTER
+};
+
+struct lz4ref_stream_decoder {
+  /* _ChunkBuffer :601-711 */
+  uint8_t *buf;
+  size_t start, end, cap;
+  int64_t max_output; /* <0 = null */
+  lz4ref_dict_resolver resolver;
+  void *user;
+  int have_resolver;
+  int finished;
+  int state;
+  uint64_t skippable_remaining;
+  uint8_t descriptor[16];
+  size_t descriptor_len;
+  int indep, block_ck, has_size, content_ck, has_dict_id;
+  size_t bmax;
+  uint64_t content_size;
+  uint32_t dict_id;
+  int have_dict; /* _dict != null */
+  const uint8_t *dict;
+  size_t dict_len;
+  uint32_t cur_size;
+  int cur_raw;
+  uint8_t *cur_data; /* _currentBlockData */
+  uint8_t history[64 * 1024];
+  size_t history_len;
+  lz4ref_xxh32_state hasher;
+  int hashing;
+  uint64_t frame_produced, total_produced;
+  uint32_t legacy_csize;
+  uint8_t *legacy_pending;
+  int legacy_has_pending;
+  size_t legacy_pending_len;
+  uint8_t *yielded; /* block handed to the caller */
+  uint8_t *work;    /* prefix + block scratch */
+  size_t work_cap;
+};
+
+lz4ref_stream_decoder *lz4ref_stream_decoder_new(int64_t max_output_bytes, lz4ref_dict_resolver resolver,
+                                                 void *user, int have_resolver) {
+  lz4ref_stream_decoder *d = (lz4ref_stream_decoder *)calloc(1, sizeof *d);
+  if (!d) return NULL;
+  d->max_output = max_output_bytes < 0 ? -1 : max_output_bytes;
+  d->resolver = resolver;
+  d->user = user;
+  d->have_resolver = have_resolver;
+  d->indep = 1;
+  d->state = SD_MAGIC;
+  return d;
+}
+
+void lz4ref_stream_decoder_free(lz4ref_stream_decoder *d) {
+  if (!d) return;
+  free(d->buf);
+  free(d->cur_data);
+  free(d->legacy_pending);
+  free(d->yielded);
+  free(d->work);
+  free(d);
+}
+
+static size_t sd_len(const lz4ref_stream_decoder *d) { return d->end - d->start; }
+static int sd_has(const lz4ref_stream_decoder *d, uint64_t n) { return sd_len(d) >= n; }
+static uint32_t sd_peek32(const lz4ref_stream_decoder *d) { return rd32(d->buf + d->start); }
+static uint32_t sd_read32(lz4ref_stream_decoder *d) {
+  uint32_t v = rd32(d->buf + d->start);
+  d->start += 4;
+  return v;
+}
+
+int lz4ref_stream_decoder_add(lz4ref_stream_decoder *d, const uint8_t *chunk, size_t n) { /* :615-622 */
+  if (n == 0) return LZ4REF_OK;
+  size_t remaining = sd_len(d);
+  if (d->start != 0) {
+    memmove(d->buf, d->buf + d->start, remaining);
+    d->start = 0;
+    d->end = remaining;
+  }
+  if (d->end + n > d->cap) {
+    size_t nc = d->cap ? d->cap : 1024;
+    while (nc < d->end + n) nc *= 2;
+    d->buf = (uint8_t *)realloc(d->buf, nc);
+    if (!d->buf) return LZ4REF_DST_TOO_SMALL;
+    d->cap = nc;
+  }
+  memcpy(d->buf + d->end, chunk, n);
+  d->end += n;
+  return LZ4REF_OK;
+}
+
+static void sd_reset_frame(lz4ref_stream_decoder *d) { /* :568-598 */
+  d->skippable_remaining = 0;
+  d->descriptor_len = 0;
+  d->indep = 1;
+  d->block_ck = d->has_size = d->content_ck = d->has_dict_id = 0;
+  d->bmax = 0;
+  d->content_size = 0;
+  d->dict_id = 0;
+  d->have_dict = 0;
+  d->dict = NULL;
+  d->dict_len = 0;
+  d->cur_size = 0;
+  d->cur_raw = 0;
+  free(d->cur_data);
+  d->cur_data = NULL;
+  d->history_len = 0;
+  d->hashing = 0;
+  d->frame_produced = 0;
+  d->legacy_csize = 0;
+  free(d->legacy_pending);
+  d->legacy_pending = NULL;
+  d->legacy_has_pending = 0;
+  d->legacy_pending_len = 0;
+}
+
+static void sd_append_history(lz4ref_stream_decoder *d, const uint8_t *bytes, size_t n) { /* :534-559 */
+  const size_t window = 64 * 1024;
+  if (n >= window) {
+    memcpy(d->history, bytes + n - window, window);
+    d->history_len = window;
+    return;
+  }
+  size_t required = d->history_len + n;
+  if (required <= window) {
+    memcpy(d->history + d->history_len, bytes, n);
+    d->history_len = required;
+    return;
+  }
+  size_t drop = required - window;
+  size_t keep = d->history_len - drop;
+  memmove(d->history, d->history + drop, keep);
+  d->history_len -= drop;
+  memcpy(d->history + d->history_len, bytes, n);
+  d->history_len += n;
+}
+
+static int sd_finish_frame(lz4ref_stream_decoder *d) { /* :561-566 */
+  if (d->has_size && d->frame_produced != d->content_size) return LZ4REF_CORRUPT_CONTENT_SIZE;
+  return LZ4REF_OK;
+}
+
+static int sd_work(lz4ref_stream_decoder *d, size_t need) {
+  if (need <= d->work_cap) return LZ4REF_OK;
+  free(d->work);
+  d->work = (uint8_t *)malloc(need);
+  d->work_cap = d->work ? need : 0;
+  return d->work ? LZ4REF_OK : LZ4REF_DST_TOO_SMALL;
+}
+
+static int sd_yield(lz4ref_stream_decoder *d, const uint8_t *p, size_t n, const uint8_t **out,
+                    size_t *out_len) {
+  free(d->yielded);
+  d->yielded = (uint8_t *)malloc(n ? n : 1);
+  if (!d->yielded) return LZ4REF_DST_TOO_SMALL;
+  memcpy(d->yielded, p, n);
+  *out = d->yielded;
+  *out_len = n;
+  return LZ4REF_OK;
+}
+
+/* _decodeCurrentBlockAndUpdateState :428-532; *n_out = 0 stands for the empty list */
+static int sd_decode_current(lz4ref_stream_decoder *d, const uint8_t **out, size_t *n_out) {
+  const size_t window = 64 * 1024;
+  const uint8_t *produced;
+  size_t produced_len;
+  int st;
+  if (d->cur_raw) { /* :432-433 */
+    produced = d->cur_data;
+    produced_len = d->cur_size;
+  } else if (d->indep) { /* :435-457 */
+    size_t eff = 0;
+    if (d->have_dict) eff = d->dict_len > window ? window : d->dict_len;
+    if ((st = sd_work(d, eff + d->bmax + 1))) return st;
+    if (eff) memcpy(d->work, d->dict + d->dict_len - eff, eff);
+    sink_t t = {d->work, eff, eff + d->bmax, (int64_t)(eff + d->bmax)};
+    if ((st = decode_into_sink(d->cur_data, d->cur_size, &t))) return st;
+    produced = d->work + eff;
+    produced_len = t.len - eff;
+  } else { /* :458-506 */
+    size_t hl = d->history_len;
+    size_t prefix = 0;
+    if ((st = sd_work(d, window + d->bmax + 1))) return st;
+    if (hl < window && d->have_dict) { /* :466-491 */
+      size_t needed = window - hl;
+      size_t cl = d->dict_len < needed ? d->dict_len : needed;
+      memcpy(d->work, d->dict + d->dict_len - cl, cl);
+      prefix = cl;
+    }
+    if (hl) memcpy(d->work + prefix, d->history, hl);
+    prefix += hl;
+    sink_t t = {d->work, prefix, prefix + d->bmax, (int64_t)(prefix + d->bmax)};
+    if ((st = decode_into_sink(d->cur_data, d->cur_size, &t))) return st;
+    if (t.len - prefix > d->bmax) return LZ4REF_CORRUPT_BLOCK_SIZE;
+    produced = d->work + prefix;
+    produced_len = t.len - prefix;
+  }
+  d->state = SD_BLOCK_SIZE; /* :510-511 */
+  *n_out = 0;
+  if (produced_len == 0) { /* :513-515 */
+    free(d->cur_data);
+    d->cur_data = NULL;
+    return LZ4REF_OK;
+  }
+  if (d->max_output >= 0 && d->total_produced + produced_len > (uint64_t)d->max_output) /* :517-520 */
+    return LZ4REF_LIMIT;
+  d->total_produced += produced_len;
+  d->frame_produced += produced_len;
+  if (d->hashing) lz4ref_xxh32_update(&d->hasher, produced, produced_len); /* :525 */
+  if (!d->indep) sd_append_history(d, produced, produced_len);            /* :527-529 */
+  st = sd_yield(d, produced, produced_len, out, n_out);
+  free(d->cur_data);
+  d->cur_data = NULL;
+  return st;
+}
+
+/* decodeNext :113-413 */
+int lz4ref_stream_decoder_next(lz4ref_stream_decoder *d, int *has_output, const uint8_t **out,
+                               size_t *out_len, uint32_t *err_dict_id) {
+  const size_t legacy_max = 8u * 1024 * 1024;
+  int st;
+  *has_output = 0;
+  *out = NULL;
+  *out_len = 0;
+  for (;;) {
+    switch (d->state) {
+      case SD_MAGIC: { /* :116-135 */
+        if (!sd_has(d, 4)) return LZ4REF_OK;
+        uint32_t magic = sd_read32(d);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) { d->state = SD_SKIP_SIZE; continue; }
+        if (magic == 0x184C2102u) { sd_reset_frame(d); d->state = SD_LEGACY_SIZE; continue; }
+        if (magic != 0x184D2204u) return LZ4REF_FORMAT_MAGIC;
+        sd_reset_frame(d);
+        d->state = SD_DESCRIPTOR;
+        continue;
+      }
+      case SD_SKIP_SIZE: /* :137-143 */
+        if (!sd_has(d, 4)) return LZ4REF_OK;
+        d->skippable_remaining = sd_read32(d);
+        d->state = SD_SKIP_SKIP;
+        continue;
+      case SD_SKIP_SKIP: { /* :145-156 */
+        if (d->skippable_remaining == 0) { d->state = SD_MAGIC; continue; }
+        size_t avail = sd_len(d);
+        size_t skipped = avail < d->skippable_remaining ? avail : (size_t)d->skippable_remaining;
+        d->start += skipped;
+        d->skippable_remaining -= skipped;
+        if (d->skippable_remaining != 0) return LZ4REF_OK;
+        d->state = SD_MAGIC;
+        continue;
+      }
+      case SD_DESCRIPTOR: { /* :158-223 */
+        if (!sd_has(d, 2)) return LZ4REF_OK;
+        uint32_t flg0 = d->buf[d->start];
+        size_t required = 2 + (((flg0 >> 3) & 1) ? 8 : 0) + ((flg0 & 1) ? 4 : 0);
+        if (!sd_has(d, required)) return LZ4REF_OK;
+        uint32_t flg = d->buf[d->start++], bd = d->buf[d->start++];
+        d->descriptor[0] = (uint8_t)flg;
+        d->descriptor[1] = (uint8_t)bd;
+        d->descriptor_len = 2;
+        if (((flg >> 6) & 3) != 1) return LZ4REF_UNSUPPORTED_VERSION;
+        d->indep = (flg >> 5) & 1;
+        d->block_ck = (flg >> 4) & 1;
+        d->has_size = (flg >> 3) & 1;
+        d->content_ck = (flg >> 2) & 1;
+        d->has_dict_id = flg & 1;
+        if ((flg >> 1) & 1) return LZ4REF_FORMAT_FLG_RESERVED;
+        if (bd & 0x8F) return LZ4REF_FORMAT_BD_RESERVED;
+        d->bmax = block_max_bytes((bd >> 4) & 7);
+        if (!d->bmax) return LZ4REF_FORMAT_BLOCK_MAX;
+        if (d->has_size) { /* :202-214 */
+          memcpy(d->descriptor + d->descriptor_len, d->buf + d->start, 8);
+          d->descriptor_len += 8;
+          uint32_t lo = sd_read32(d), hi = sd_read32(d);
+          uint64_t val = ((uint64_t)hi << 32) + lo;
+          if (val >> 63) return LZ4REF_UNSUPPORTED_CONTENT_SIZE; /* val < 0 */
+          d->content_size = val;
+        }
+        if (d->has_dict_id) { /* :216-220 */
+          memcpy(d->descriptor + d->descriptor_len, d->buf + d->start, 4);
+          d->descriptor_len += 4;
+          d->dict_id = sd_read32(d);
+        }
+        d->state = SD_HEADER_CK;
+        continue;
+      }
+      case SD_HEADER_CK: { /* :225-253 */
+        if (!sd_has(d, 1)) return LZ4REF_OK;
+        uint32_t hc = d->buf[d->start++];
+        if (hc != ((lz4ref_xxh32(d->descriptor, d->descriptor_len, 0) >> 8) & 0xff))
+          return LZ4REF_CORRUPT_HEADER_CK;
+        if (d->has_dict_id) {
+          if (!d->have_resolver) return LZ4REF_UNSUPPORTED_DICT;
+          const uint8_t *dp = NULL;
+          size_t dl = 0;
+          if (!d->resolver(d->user, d->dict_id, &dp, &dl)) {
+            if (err_dict_id) *err_dict_id = d->dict_id;
+            return LZ4REF_DICT_NOT_FOUND;
+          }
+          d->have_dict = 1;
+          d->dict = dp;
+          d->dict_len = dl;
+        }
+        d->hashing = d->content_ck;
+        if (d->hashing) lz4ref_xxh32_init(&d->hasher, 0);
+        d->state = SD_BLOCK_SIZE;
+        continue;
+      }
+      case SD_BLOCK_SIZE: { /* :255-278 */
+        if (!sd_has(d, 4)) return LZ4REF_OK;
+        uint32_t raw = sd_read32(d);
+        if (raw == 0) {
+          if (d->content_ck) { d->state = SD_CONTENT_CK; continue; }
+          if ((st = sd_finish_frame(d))) return st;
+          d->state = SD_MAGIC;
+          continue;
+        }
+        d->cur_raw = (raw & 0x80000000u) != 0;
+        d->cur_size = raw & 0x7FFFFFFFu;
+        if (d->cur_size > d->bmax) return LZ4REF_CORRUPT_BLOCK_SIZE;
+        d->state = SD_BLOCK_DATA;
+        continue;
+      }
+      case SD_BLOCK_DATA: { /* :280-295 */
+        if (!sd_has(d, d->cur_size)) return LZ4REF_OK;
+        free(d->cur_data);
+        d->cur_data = (uint8_t *)malloc(d->cur_size ? d->cur_size : 1);
+        if (!d->cur_data) return LZ4REF_DST_TOO_SMALL;
+        memcpy(d->cur_data, d->buf + d->start, d->cur_size);
+        d->start += d->cur_size;
+        if (d->block_ck) { d->state = SD_BLOCK_CK; continue; }
+        if ((st = sd_decode_current(d, out, out_len))) return st;
+        if (*out_len) { *has_output = 1; return LZ4REF_OK; }
+        continue;
+      }
+      case SD_BLOCK_CK: { /* :297-312 */
+        if (!sd_has(d, 4)) return LZ4REF_OK;
+        uint32_t expected = sd_read32(d);
+        if (lz4ref_xxh32(d->cur_data, d->cur_size, 0) != expected) return LZ4REF_CORRUPT_BLOCK_CK;
+        if ((st = sd_decode_current(d, out, out_len))) return st;
+        if (*out_len) { *has_output = 1; return LZ4REF_OK; }
+        continue;
+      }
+      case SD_CONTENT_CK: { /* :314-326 */
+        if (!sd_has(d, 4)) return LZ4REF_OK;
+        uint32_t expected = sd_read32(d);
+        uint32_t actual = d->hashing ? lz4ref_xxh32_digest(&d->hasher) : 0;
+        if (actual != expected) return LZ4REF_CORRUPT_CONTENT_CK;
+        if ((st = sd_finish_frame(d))) return st;
+        d->state = SD_MAGIC;
+        continue;
+      }
+      case SD_LEGACY_SIZE: { /* :328-354 */
+        if (d->legacy_has_pending) { d->state = SD_LEGACY_AFTER; continue; }
+        if (!sd_has(d, 4)) {
+          if (d->finished) { d->state = SD_MAGIC; continue; }
+          return LZ4REF_OK;
+        }
+        if (is_legacy_boundary(sd_peek32(d))) { d->state = SD_MAGIC; continue; }
+        uint32_t csize = sd_read32(d);
+        if (csize == 0) return LZ4REF_CORRUPT_LEGACY_SIZE;
+        d->legacy_csize = csize;
+        d->state = SD_LEGACY_DATA;
+        continue;
+      }
+      case SD_LEGACY_DATA: { /* :356-376 */
+        if (!sd_has(d, d->legacy_csize)) return LZ4REF_OK;
+        const uint8_t *block = d->buf + d->start;
+        d->start += d->legacy_csize;
+        free(d->legacy_pending);
+        d->legacy_pending = (uint8_t *)malloc(legacy_max);
+        if (!d->legacy_pending) return LZ4REF_DST_TOO_SMALL;
+        sink_t t = {d->legacy_pending, 0, legacy_max, (int64_t)legacy_max};
+        if ((st = decode_into_sink(block, d->legacy_csize, &t))) return st;
+        if (d->max_output >= 0 && d->total_produced + t.len > (uint64_t)d->max_output) return LZ4REF_LIMIT;
+        d->total_produced += t.len;
+        d->legacy_has_pending = 1;
+        d->legacy_pending_len = t.len;
+        d->state = SD_LEGACY_AFTER;
+        continue;
+      }
+      case SD_LEGACY_AFTER: { /* :378-410 */
+        if (!d->legacy_has_pending) { d->state = SD_LEGACY_SIZE; continue; }
+        int next_state;
+        if (!sd_has(d, 4)) {
+          if (!d->finished) return LZ4REF_OK;
+          next_state = SD_MAGIC;
+        } else if (is_legacy_boundary(sd_peek32(d))) {
+          next_state = SD_MAGIC;
+        } else {
+          if (d->legacy_pending_len != legacy_max) return LZ4REF_CORRUPT_LEGACY_NOT_FULL;
+          next_state = SD_LEGACY_SIZE;
+        }
+        if ((st = sd_yield(d, d->legacy_pending, d->legacy_pending_len, out, out_len))) return st;
+        free(d->legacy_pending);
+        d->legacy_pending = NULL;
+        d->legacy_has_pending = 0;
+        d->legacy_pending_len = 0;
+        d->state = next_state;
+        *has_output = 1; /* the pending list is yielded even when empty */
+        return LZ4REF_OK;
+      }
+    }
+  }
+}
+
+int lz4ref_stream_decoder_finish(lz4ref_stream_decoder *d) { /* :415-426 */
+  d->finished = 1;
+  if (sd_len(d) == 0 && d->state == SD_MAGIC) return LZ4REF_OK;
+  if (d->state == SD_LEGACY_AFTER && d->legacy_has_pending) {
+    if (sd_len(d) == 0) return LZ4REF_OK;
+  }
+  return LZ4REF_FORMAT_EOF;
 }

@@ -37,6 +37,8 @@ enum {
   LZ4REF_FORMAT_BLOCK_MAX = 5,      /* 'Invalid block maximum size' :396 */
   LZ4REF_FORMAT_INT_OVERFLOW = 6,   /* 'Integer overflow'          byte_reader.dart:75 */
   LZ4REF_FORMAT_CONTENT_SIZE_ARG = 7, /* 'contentSize does not match src length' lz4_frame_encoder.dart:270 */
+  LZ4REF_FORMAT_CONTENT_SIZE_STREAM = 8, /* 'contentSize does not match stream length' lz4_frame_stream_encoder.dart:166,225 */
+  LZ4REF_FORMAT_SIZE_HEADER = 9,    /* 'Input too short for size header' block/lz4_sized_block.dart:41 */
   /* Lz4CorruptDataException */
   LZ4REF_CORRUPT_LITERAL = 10,      /* 'Literal length exceeds output size' lz4_block_decoder.dart:34 */
   LZ4REF_CORRUPT_MATCH = 11,        /* 'Match length exceeds output size'   :62 */
@@ -54,6 +56,7 @@ enum {
   /* Lz4UnsupportedFeatureException */
   LZ4REF_UNSUPPORTED_VERSION = 40,  /* 'Unsupported LZ4 frame version' lz4_frame_decoder.dart:177 */
   LZ4REF_UNSUPPORTED_DICT = 41,     /* 'Dictionary ID present but no dictionary resolver provided' :228 */
+  LZ4REF_UNSUPPORTED_CONTENT_SIZE = 42, /* 'Content size exceeds supported integer range' lz4_frame_stream_decoder.dart:210 */
   /* base Lz4Exception */
   LZ4REF_DICT_NOT_FOUND = 50,       /* 'Dictionary not found for ID: <id>' :233 */
   /* Dart RangeError (argument validation) */
@@ -135,6 +138,61 @@ int lz4ref_frame_decode(const uint8_t *src, size_t len,
                         lz4ref_dict_resolver resolver, void *user,
                         uint8_t *dst, size_t cap, size_t *out_len,
                         uint32_t *err_dict_id);
+
+/* ---- host-only formats ---- */
+
+/* Lz4FrameInfo (frame/lz4_frame_info.dart:13-63); has_* stand for nullable fields. */
+typedef struct {
+  uint32_t magic;
+  int32_t is_skippable, is_legacy;
+  int32_t block_independence, block_checksum, content_checksum;
+  int32_t has_content_size, has_dict_id;
+  uint32_t skippable_size, dict_id, block_max_size, header_size;
+  uint64_t content_size;
+} lz4ref_frame_info_t;
+
+int lz4ref_frame_info(const uint8_t *src, size_t len, lz4ref_frame_info_t *out); /* :89-199 */
+
+/* lz4SkippableFrameEncode (frame/lz4_frame_encoder.dart:27-46) */
+int lz4ref_skippable_frame_encode(const uint8_t *data, size_t n, int index,
+                                  uint8_t *dst, size_t cap, size_t *out_len);
+/* lz4LegacyFrameEncode (:55-89) */
+size_t lz4ref_legacy_frame_bound(size_t n);
+int lz4ref_legacy_frame_encode(const uint8_t *src, size_t n, int64_t acceleration,
+                               uint8_t *dst, size_t cap, size_t *out_len);
+/* lz4CompressWithSize / lz4DecompressWithSize (block/lz4_sized_block.dart:15-55);
+ * level 0 = fast (param = acceleration), 1 = hc (param = maxSearchDepth, default options). */
+int lz4ref_compress_with_size(const uint8_t *src, size_t n, int level, int64_t param,
+                              uint8_t *dst, size_t cap, size_t *out_len);
+int lz4ref_decompress_with_size(const uint8_t *src, size_t len, uint8_t *dst, size_t cap,
+                                size_t *out_len);
+
+/* ---- streaming transformers ----
+ * Encoder: frame/lz4_frame_stream_encoder.dart:25-236.  Every call appends the
+ * pieces the transformer would yield to dst and records each piece's length.
+ * When a call fails, *out_len / *npieces cover what was yielded before the throw. */
+typedef struct lz4ref_stream_encoder lz4ref_stream_encoder;
+lz4ref_stream_encoder *lz4ref_stream_encoder_new(const lz4ref_frame_options *o,
+                                                 const uint8_t *dict, size_t dict_len, int *status);
+int lz4ref_stream_encoder_header(lz4ref_stream_encoder *e, uint8_t *dst, size_t cap, size_t *out_len);
+int lz4ref_stream_encoder_add(lz4ref_stream_encoder *e, const uint8_t *chunk, size_t n,
+                              uint8_t *dst, size_t cap, size_t *out_len,
+                              uint32_t *piece_lens, size_t piece_cap, size_t *npieces);
+int lz4ref_stream_encoder_close(lz4ref_stream_encoder *e, uint8_t *dst, size_t cap, size_t *out_len,
+                                uint32_t *piece_lens, size_t piece_cap, size_t *npieces);
+void lz4ref_stream_encoder_free(lz4ref_stream_encoder *e);
+
+/* Decoder: frame/lz4_frame_stream_decoder.dart:62-599.  next() is decodeNext():
+ * *has_output = 0 stands for a null return; the block stays valid until the next call. */
+typedef struct lz4ref_stream_decoder lz4ref_stream_decoder;
+lz4ref_stream_decoder *lz4ref_stream_decoder_new(int64_t max_output_bytes,
+                                                 lz4ref_dict_resolver resolver, void *user,
+                                                 int have_resolver);
+int lz4ref_stream_decoder_add(lz4ref_stream_decoder *d, const uint8_t *chunk, size_t n);
+int lz4ref_stream_decoder_next(lz4ref_stream_decoder *d, int *has_output, const uint8_t **out,
+                               size_t *out_len, uint32_t *err_dict_id);
+int lz4ref_stream_decoder_finish(lz4ref_stream_decoder *d);
+void lz4ref_stream_decoder_free(lz4ref_stream_decoder *d);
 
 #ifdef __cplusplus
 }

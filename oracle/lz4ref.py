@@ -57,6 +57,16 @@ class _XxhState(C.Structure):
     ]
 
 
+class FrameInfo(C.Structure):
+    _fields_ = [
+        ("magic", C.c_uint32), ("is_skippable", C.c_int32), ("is_legacy", C.c_int32),
+        ("block_independence", C.c_int32), ("block_checksum", C.c_int32), ("content_checksum", C.c_int32),
+        ("has_content_size", C.c_int32), ("has_dict_id", C.c_int32), ("skippable_size", C.c_uint32),
+        ("dict_id", C.c_uint32), ("block_max_size", C.c_uint32), ("header_size", C.c_uint32),
+        ("content_size", C.c_uint64),
+    ]
+
+
 _RESOLVER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
 
 _lib = None
@@ -93,6 +103,31 @@ def lib():
         L.lz4ref_frame_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int64, _RESOLVER, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
                                           C.POINTER(C.c_uint32)]
+        sz, psz, u8 = C.c_size_t, C.POINTER(C.c_size_t), C.c_char_p
+        L.lz4ref_frame_info.argtypes = [u8, sz, C.POINTER(FrameInfo)]
+        L.lz4ref_skippable_frame_encode.argtypes = [u8, sz, C.c_int, C.c_void_p, sz, psz]
+        L.lz4ref_legacy_frame_bound.restype = sz
+        L.lz4ref_legacy_frame_bound.argtypes = [sz]
+        L.lz4ref_legacy_frame_encode.argtypes = [u8, sz, C.c_int64, C.c_void_p, sz, psz]
+        L.lz4ref_compress_with_size.argtypes = [u8, sz, C.c_int, C.c_int64, C.c_void_p, sz, psz]
+        L.lz4ref_decompress_with_size.argtypes = [u8, sz, C.c_void_p, sz, psz]
+        L.lz4ref_stream_encoder_new.restype = C.c_void_p
+        L.lz4ref_stream_encoder_new.argtypes = [C.POINTER(FrameOptions), u8, sz, C.POINTER(C.c_int)]
+        L.lz4ref_stream_encoder_header.argtypes = [C.c_void_p, C.c_void_p, sz, psz]
+        L.lz4ref_stream_encoder_add.argtypes = [C.c_void_p, u8, sz, C.c_void_p, sz, psz,
+                                                C.POINTER(C.c_uint32), sz, psz]
+        L.lz4ref_stream_encoder_close.argtypes = [C.c_void_p, C.c_void_p, sz, psz, C.POINTER(C.c_uint32), sz,
+                                                  psz]
+        L.lz4ref_stream_encoder_free.argtypes = [C.c_void_p]
+        L.lz4ref_stream_encoder_free.restype = None
+        L.lz4ref_stream_decoder_new.restype = C.c_void_p
+        L.lz4ref_stream_decoder_new.argtypes = [C.c_int64, _RESOLVER, C.c_void_p, C.c_int]
+        L.lz4ref_stream_decoder_add.argtypes = [C.c_void_p, u8, sz]
+        L.lz4ref_stream_decoder_next.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p), psz,
+                                                 C.POINTER(C.c_uint32)]
+        L.lz4ref_stream_decoder_finish.argtypes = [C.c_void_p]
+        L.lz4ref_stream_decoder_free.argtypes = [C.c_void_p]
+        L.lz4ref_stream_decoder_free.restype = None
         _lib = L
     return _lib
 
@@ -239,3 +274,181 @@ def frame_decode(src: bytes, max_output_bytes: int | None = None, dictionary_res
     if st:
         _raise(st, err_id.value)
     return dst.raw[: out.value]
+
+
+# ------------------------------------------------------------ host-only formats
+
+def frame_info(src: bytes) -> dict:
+    """lz4FrameInfo (lib/src/frame/lz4_frame_info.dart:89-199) as a dict of the struct fields."""
+    src = bytes(src)
+    info = FrameInfo()
+    st = lib().lz4ref_frame_info(src, len(src), C.byref(info))
+    if st:
+        _raise(st)
+    return {name: getattr(info, name) for name, _ in FrameInfo._fields_}
+
+
+def skippable_frame_encode(data: bytes, index: int = 0) -> bytes:
+    """lz4SkippableFrameEncode (lib/src/frame/lz4_frame_encoder.dart:27-46)."""
+    data = bytes(data)
+    cap = 8 + len(data)
+    dst = C.create_string_buffer(cap)
+    out = C.c_size_t(0)
+    st = lib().lz4ref_skippable_frame_encode(data, len(data), index, dst, cap, C.byref(out))
+    if st:
+        _raise(st)
+    return dst.raw[: out.value]
+
+
+def legacy_frame_encode(src: bytes, acceleration: int = 1) -> bytes:
+    """lz4LegacyFrameEncode (lib/src/frame/lz4_frame_encoder.dart:55-89)."""
+    src = bytes(src)
+    cap = lib().lz4ref_legacy_frame_bound(len(src))
+    dst = C.create_string_buffer(cap)
+    out = C.c_size_t(0)
+    st = lib().lz4ref_legacy_frame_encode(src, len(src), acceleration, dst, cap, C.byref(out))
+    if st:
+        _raise(st)
+    return dst.raw[: out.value]
+
+
+def compress_with_size(src: bytes, level: int = 0, param: int | None = None) -> bytes:
+    """lz4CompressWithSize (lib/src/block/lz4_sized_block.dart:15-31); level 0 fast, 1 hc."""
+    src = bytes(src)
+    if param is None:
+        param = 1 if level == 0 else 64
+    cap = compress_bound(len(src)) + 20
+    dst = C.create_string_buffer(cap)
+    out = C.c_size_t(0)
+    st = lib().lz4ref_compress_with_size(src, len(src), level, param, dst, cap, C.byref(out))
+    if st:
+        _raise(st)
+    return dst.raw[: out.value]
+
+
+def decompress_with_size(src: bytes) -> bytes:
+    """lz4DecompressWithSize (lib/src/block/lz4_sized_block.dart:39-55)."""
+    src = bytes(src)
+    cap = int.from_bytes(src[:4], "little") if len(src) >= 4 else 0
+    dst = C.create_string_buffer(max(cap, 1))
+    out = C.c_size_t(0)
+    st = lib().lz4ref_decompress_with_size(src, len(src), dst, cap, C.byref(out))
+    if st:
+        _raise(st)
+    return dst.raw[: out.value]
+
+
+# ------------------------------------------------------------------- streaming
+
+def stream_encode(chunks, options: FrameOptions | None = None, dictionary=None):
+    """lz4FrameEncoderTransformerWithOptions (lib/src/frame/lz4_frame_stream_encoder.dart:25-236).
+
+    Returns (pieces, error): the list of yielded chunks and the Lz4RefError that ended the
+    stream, or None."""
+    L = lib()
+    o = options if options is not None else frame_options()
+    d = bytes(dictionary) if dictionary is not None else None
+    status = C.c_int(0)
+    e = L.lz4ref_stream_encoder_new(C.byref(o), d, len(d) if d is not None else 0, C.byref(status))
+    if not e:
+        _raise(status.value)
+    pieces: list[bytes] = []
+    bmax = {4: 64 << 10, 5: 256 << 10, 6: 1 << 20, 7: 4 << 20}[o.block_size_id]
+    try:
+        hdr = C.create_string_buffer(32)
+        out = C.c_size_t(0)
+        st = L.lz4ref_stream_encoder_header(e, hdr, 32, C.byref(out))
+        if st:
+            _raise(st)
+        pieces.append(hdr.raw[: out.value])
+        pending = 0
+
+        def collect(dst, n_out, lens, n_pieces):
+            pos = 0
+            for k in range(n_pieces):
+                pieces.append(dst.raw[pos: pos + lens[k]])
+                pos += lens[k]
+            assert pos == n_out
+
+        for chunk in chunks:
+            chunk = bytes(chunk)
+            nblk = (pending + len(chunk)) // bmax + 1
+            cap = nblk * (bmax + 8) + compress_bound(bmax) + 64
+            dst = C.create_string_buffer(cap)
+            lens = (C.c_uint32 * (nblk + 4))()
+            npieces = C.c_size_t(0)
+            st = L.lz4ref_stream_encoder_add(e, chunk, len(chunk), dst, cap, C.byref(out), lens, nblk + 4,
+                                             C.byref(npieces))
+            collect(dst, out.value, lens, npieces.value)
+            if st:
+                return pieces, Lz4RefError(st, L.lz4ref_status_type(st).decode(),
+                                           L.lz4ref_status_message(st).decode())
+            pending = (pending + len(chunk)) % bmax
+        cap = bmax + compress_bound(bmax) + 64
+        dst = C.create_string_buffer(cap)
+        lens = (C.c_uint32 * 8)()
+        npieces = C.c_size_t(0)
+        st = L.lz4ref_stream_encoder_close(e, dst, cap, C.byref(out), lens, 8, C.byref(npieces))
+        collect(dst, out.value, lens, npieces.value)
+        if st:
+            return pieces, Lz4RefError(st, L.lz4ref_status_type(st).decode(),
+                                       L.lz4ref_status_message(st).decode())
+        return pieces, None
+    finally:
+        L.lz4ref_stream_encoder_free(e)
+
+
+def stream_decode(chunks, max_output_bytes: int | None = None, dictionary_resolver=None):
+    """lz4FrameDecoderTransformer (lib/src/frame/lz4_frame_stream_decoder.dart:15-45).
+
+    Returns (pieces, error) like stream_encode."""
+    L = lib()
+    keep = []
+
+    def _cb(_user, dict_id, pp, plen):
+        dd = dictionary_resolver(dict_id)
+        if dd is None:
+            return 0
+        b = C.create_string_buffer(bytes(dd), max(len(dd), 1))
+        keep.append(b)
+        pp[0] = C.cast(b, C.c_void_p).value
+        plen[0] = len(dd)
+        return 1
+
+    cb = _RESOLVER(_cb) if dictionary_resolver is not None else C.cast(None, _RESOLVER)
+    d = L.lz4ref_stream_decoder_new(-1 if max_output_bytes is None else max_output_bytes, cb, None,
+                                    int(dictionary_resolver is not None))
+    pieces: list[bytes] = []
+    has, ptr, n, err_id = C.c_int(0), C.c_void_p(), C.c_size_t(0), C.c_uint32(0)
+
+    def err(st):
+        msg = L.lz4ref_status_message(st).decode()
+        if st == 50:
+            msg += str(err_id.value)
+        return Lz4RefError(st, L.lz4ref_status_type(st).decode(), msg)
+
+    def drain():
+        while True:
+            st = L.lz4ref_stream_decoder_next(d, C.byref(has), C.byref(ptr), C.byref(n), C.byref(err_id))
+            if st:
+                return st
+            if not has.value:
+                return 0
+            pieces.append(C.string_at(ptr.value, n.value) if n.value else b"")
+
+    try:
+        for chunk in chunks:
+            chunk = bytes(chunk)
+            L.lz4ref_stream_decoder_add(d, chunk, len(chunk))
+            st = drain()
+            if st:
+                return pieces, err(st)
+        st = L.lz4ref_stream_decoder_finish(d)
+        if st:
+            return pieces, err(st)
+        st = drain()
+        if st:
+            return pieces, err(st)
+        return pieces, None
+    finally:
+        L.lz4ref_stream_decoder_free(d)

@@ -36,6 +36,9 @@ def test_status_strings_match_reference_messages():
         5: ("Lz4FormatException", "Invalid block maximum size"),
         6: ("Lz4FormatException", "Integer overflow"),
         7: ("Lz4FormatException", "contentSize does not match src length"),
+        8: ("Lz4FormatException", "contentSize does not match stream length"),
+        9: ("Lz4FormatException", "Input too short for size header"),
+        42: ("Lz4UnsupportedFeatureException", "Content size exceeds supported integer range"),
         10: ("Lz4CorruptDataException", "Literal length exceeds output size"),
         11: ("Lz4CorruptDataException", "Match length exceeds output size"),
         12: ("Lz4CorruptDataException", "Trailing bytes after end of block"),
@@ -58,7 +61,7 @@ def test_status_strings_match_reference_messages():
 def test_product_and_oracle_agree_on_status_codes(oracle):
     from lz4_amd import _native as N
     L, R = N.load(), oracle.lib()
-    for code in list(range(0, 8)) + list(range(10, 21)) + [30, 40, 41, 50]:
+    for code in list(range(0, 10)) + list(range(10, 21)) + [30, 40, 41, 42, 50]:
         assert L.lz4mi_status_message(code) == R.lz4ref_status_message(code)
 
 
@@ -151,3 +154,72 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "lz4ref" not in text and "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_frame_info_and_skippable_encode_match_oracle(oracle):
+    """Host-only entry points (no GPU work): lz4mi_frame_info_parse and
+    lz4mi_skippable_frame_encode against the oracle, including the reference's own cases
+    (test/frame/lz4_frame_info_test.dart:8-91, lz4_skippable_frame_test.dart:8-98)."""
+    import lz4_amd
+    from tests.helpers import golden, golden_frame
+    frames = [golden_frame(n)[0] for n in golden()["lz4_cli_frames"]]
+    frames.append(oracle.frame_encode(bytes(100), oracle.frame_options(content_size=100, content_checksum=True)))
+    frames.append(oracle.frame_encode(b"x", oracle.frame_options(block_size_id=5, dict_id=0xFFFFFFFF,
+                                                                  block_independence=False, block_checksum=True)))
+    frames.append(bytes([0x50, 0x2A, 0x4D, 0x18, 4, 0, 0, 0, 1, 2, 3, 4]))
+    frames.append(bytes([0x02, 0x21, 0x4C, 0x18]))
+    for f in frames:
+        want = oracle.frame_info(f)
+        got = lz4_amd.lz4FrameInfo(f)
+        assert got.magic == want["magic"] and got.headerSize == want["header_size"]
+        assert got.isSkippable == bool(want["is_skippable"]) and got.isLegacy == bool(want["is_legacy"])
+        assert got.blockIndependence == bool(want["block_independence"])
+        assert got.blockChecksum == bool(want["block_checksum"])
+        assert got.contentChecksum == bool(want["content_checksum"])
+        assert got.contentSize == (want["content_size"] if want["has_content_size"] else None)
+        assert got.dictId == (want["dict_id"] if want["has_dict_id"] else None)
+        assert got.blockMaxSize == want["block_max_size"]
+        if got.isSkippable:
+            assert got.skippableSize == want["skippable_size"]
+    # every truncation and every single-byte corruption of a full header fails identically
+    full = frames[-4][:15]
+    variants = [full[:k] for k in range(16)]
+    for k in range(4, 15):
+        for bit in (0x01, 0x02, 0x40, 0x80):
+            v = bytearray(full)
+            v[k] ^= bit
+            variants.append(bytes(v))
+    for v in variants:
+        try:
+            want = ("ok", oracle.frame_info(v)["header_size"])
+        except oracle.Lz4RefError as e:
+            want = (e.type_name, e.message)
+        try:
+            got = ("ok", lz4_amd.lz4FrameInfo(v).headerSize)
+        except lz4_amd.Lz4Exception as e:
+            got = (type(e).__name__, e.message)
+        assert got == want, v.hex()
+    assert str(lz4_amd.lz4FrameInfo(frames[-2])) == "Lz4FrameInfo(type: skippable, size: 4)"
+    assert str(lz4_amd.lz4FrameInfo(frames[-1])) == "Lz4FrameInfo(type: legacy)"
+    for data, index in ((b"", 0), (bytes([1, 2, 3, 4, 5]), 0), (bytes([0xAB, 0xCD]), 15), (bytes(1000), 7)):
+        assert lz4_amd.lz4SkippableEncode(data, index=index) == oracle.skippable_frame_encode(data, index)
+    assert lz4_amd.lz4SkippableEncode(bytes([0xAB, 0xCD]), index=15) == bytes(
+        [0x5F, 0x2A, 0x4D, 0x18, 2, 0, 0, 0, 0xAB, 0xCD])
+    import pytest
+    for bad in (-1, 16):
+        with pytest.raises(lz4_amd.RangeError):
+            lz4_amd.lz4SkippableEncode(b"", index=bad)
+
+
+def test_xxh32_state_digest_of_short_inputs_needs_no_gpu(oracle):
+    """Inputs below one stripe never reach the device: init/update/digest are host arithmetic
+    on the caller's struct (lib/src/xxhash/xxh32.dart:60-64,127-163)."""
+    import ctypes as C
+    from lz4_amd import _native as N
+    L = N.load()
+    for data in (b"", b"a", b"abc", b"0123456789abcde"):
+        s = N.XxhState()
+        L.lz4mi_xxh32_state_init(C.byref(s), 0)
+        for k in range(len(data)):  # one byte at a time: the carry path only
+            assert L.lz4mi_xxh32_state_update(None, C.byref(s), data[k:k + 1], 1) == 0
+        assert L.lz4mi_xxh32_state_digest(C.byref(s)) == oracle.xxh32(data)
