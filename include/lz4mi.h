@@ -205,6 +205,13 @@ typedef struct {
   int32_t hc_max_search_depth;/* default 64 */
   uint32_t dict_id;
   uint64_t content_size;
+  /* Not a reference option (default 0).  Nonzero: every block obeys the lz4 block format's
+   * end-of-block rules (no match starts in the last 12 bytes, the last 5 bytes are literals,
+   * blocks under 13 bytes are literals only), so the frame decodes with any LZ4 decoder.
+   * The reference's encoders end blocks inside matches, which the lz4 CLI rejects; with this
+   * flag the output is no longer byte-identical to the reference's. */
+  int32_t spec_conformant;
+  int32_t reserved;
 } lz4mi_frame_options;
 
 void lz4mi_frame_options_default(lz4mi_frame_options *o);

@@ -45,6 +45,7 @@ class FrameOptions(C.Structure):
         ("content_checksum", C.c_int32), ("has_content_size", C.c_int32), ("has_dict_id", C.c_int32),
         ("compression", C.c_int32), ("acceleration", C.c_int32), ("hc_max_search_depth", C.c_int32),
         ("dict_id", C.c_uint32), ("content_size", C.c_uint64),
+        ("spec_conformant", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -101,6 +101,7 @@ def _c_options(options: Lz4FrameOptions) -> N.FrameOptions:
     o.compression = options.compression.value
     o.acceleration = min(options.acceleration, 0x7FFFFFFF)
     o.hc_max_search_depth = min((options.hcOptions or Lz4HcOptions()).maxSearchDepth, 0x7FFFFFFF)
+    o.spec_conformant = int(options.specConformantBlocks)
     return o
 
 

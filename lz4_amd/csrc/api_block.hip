@@ -224,6 +224,7 @@ static void to_args(const lz4mi_batch *b, BatchArgs &a) {
   a.out_len = b->d_out_len;
   a.status = b->d_status;
   a.linked = 0;
+  a.conformant = 0;
 }
 
 }  // namespace lz4mi

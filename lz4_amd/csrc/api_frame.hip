@@ -91,6 +91,7 @@ int32_t shard_compress(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4
   a.dict = d_dict;
   a.dict_len = d_dict ? dict_len : 0;
   a.linked = o->block_independence ? 0u : 1u;
+  a.conformant = o->spec_conformant ? 1u : 0u;
   a.nblocks = nb;
   a.out_len = c->comp_len.as<uint32_t>();
   a.status = c->status.as<int32_t>();

@@ -14,7 +14,23 @@ struct EncIn {
   const uint8_t *src;   // block bytes (positions [D, total))
   uint32_t D;
   uint32_t total;
+  // End-of-block limits: a position p is searched while p + 4 <= plimit and a match may run up
+  // to elimit.  Both equal `total` for the reference's behaviour (:95, :117-121); the optional
+  // spec-conformant mode pulls them in (no match starts in the last 12 bytes, the last 5 bytes
+  // stay literals, blocks under 13 bytes are literals only).
+  uint32_t plimit;
+  uint32_t elimit;
 };
+
+__device__ __forceinline__ void set_end_limits(EncIn &in, uint32_t conformant) {
+  const uint32_t n = in.total - in.D;
+  in.plimit = in.total;
+  in.elimit = in.total;
+  if (conformant) {
+    in.plimit = n >= 13 ? in.total - 8 : 0u;
+    in.elimit = n >= 5 ? in.total - 5 : 0u;
+  }
+}
 
 template <bool HAS_DICT>
 __device__ __forceinline__ uint32_t in_byte(const EncIn &in, uint32_t pos) {

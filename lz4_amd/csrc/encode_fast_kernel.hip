@@ -197,6 +197,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
                                                      lds_u32 *claim, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
+  const uint32_t plimit = in.plimit, elimit = in.elimit;
   const uint32_t n = total - D;
   out_len = 0;
   if (n == 0) return LZ4MI_OK;  // :45-48
@@ -215,7 +216,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       }
     }
     Win w = {lds, in.src, n, 0, 0};
-    while (anchor + 4 <= total) {  // one iteration per sequence
+    while (anchor + 4 <= plimit) {  // one iteration per sequence
       const uint32_t s = anchor - D;
       {
         const uint32_t need = s + kLead < n ? s + kLead : n;
@@ -229,7 +230,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
 
       // ---- first kFirst probes of the run (:95-103): bytes from the ring
       uint32_t ik = anchor + offA;
-      bool valid = lane < kFirst && ik + 4 <= total;
+      bool valid = lane < kFirst && ik + 4 <= plimit;
       uint32_t seq = w32(w, ik - D);
       uint32_t h = hash16(seq);
       int32_t ref = -1;
@@ -288,7 +289,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
               if (t <= lane) o = sched_next(o, sh);
           }
           ik = anchor + o;
-          valid = ik + 4 <= total;  // a prefix of the lanes
+          valid = ik + 4 <= plimit;  // a prefix of the lanes
           nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
           if (nvalid == 0) break;
           PH_CNT(8);
@@ -324,7 +325,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         }
         vm_quiesce();
       }
-      if (!hm) break;  // the schedule ran past total - 4 without a hit
+      if (!hm) break;  // the schedule ran past the last searched position without a hit
       PH(14);
 
       // ---- match at lane K
@@ -342,10 +343,10 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         const uint32_t pp = lane < 32 ? i - 1 - lane : i + 4 + 8 * (lane - 32);
         const uint64_t x = w64(w, pp - D) ^ w64(w, pp - dist - D);
         const uint32_t e8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-        const uint32_t avail = pp < total ? total - pp : 0u;  // bytes past the block end never count
+        const uint32_t avail = pp < elimit ? elimit - pp : 0u;  // bytes past the match limit never count
         eq = e8 < avail ? e8 : avail;
         stop = lane < 32 ? !(lane < maxb && e8 != 0) : eq < 8;
-      } else if (r0 >= D + 32 && i + 272 <= total && i - D + 272 <= w.hi) {
+      } else if (r0 >= D + 32 && i + 272 <= elimit && i - D + 272 <= w.hi) {
         // reference outside the ring: its side comes from memory (one unconditional 8-byte load per lane)
         PH_CNT(11);
         const uint32_t pp = lane < 32 ? i - 1 - lane : i + 4 + 8 * (lane - 32);
@@ -358,7 +359,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           stop = !(lane < maxb && rd8<HAS_DICT>(in, w, i - 1 - lane) == rd8<HAS_DICT>(in, w, r0 - 1 - lane));
         } else {
           const uint32_t pp = i + 4 + 8 * (lane - 32);
-          eq = eq8<HAS_DICT>(in, w, pp, pp - dist, total);
+          eq = eq8<HAS_DICT>(in, w, pp, pp - dist, elimit);
           stop = eq < 8;
         }
       }
@@ -381,7 +382,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         fwd = 256;
         for (;;) {
           const uint32_t pp = i + 4 + fwd + 16 * lane;
-          const uint32_t e16 = eq16g<HAS_DICT>(in, w, pp, pp - dist, total);
+          const uint32_t e16 = eq16g<HAS_DICT>(in, w, pp, pp - dist, elimit);
           const uint64_t m = ballot(e16 < 16);
           if (m) {
             const uint32_t L = (uint32_t)__builtin_ctzll(m);
@@ -427,7 +428,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       PH(6);
 
       // ---- :135-145 interior re-hash, last `dist` positions only
-      if (anchor + 4 <= total) {
+      if (anchor + 4 <= plimit) {
         const uint32_t hi = anchor - 4;
         uint32_t lo = ms + 1;
         if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
       in.D = b == 0 ? a.dict_len : 65535u;
     }
     in.total = in.D + uni(block_src_len(a, b));
+    set_end_limits(in, a.conformant);
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;

@@ -249,6 +249,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
                                                    const HcIndex x, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
+  const uint32_t plimit = in.plimit, elimit = in.elimit;  // both == total unless spec-conformant
   const uint32_t n = total - D;
   out_len = 0;
   if (n == 0) return LZ4MI_OK;  // :57-60
@@ -258,9 +259,9 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
 
   if (n >= 4) {  // :86-90
     hc_build_index<HAS_DICT>(in, x, total - 3, lane);
-    while (i + 4 <= total) {  // :116
+    while (i + 4 <= plimit) {  // :116
       const uint32_t p = i + lane;
-      const bool valid = p + 4 <= total;  // a prefix of the lanes
+      const bool valid = p + 4 <= plimit;  // a prefix of the lanes
       const uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
       uint32_t seq = 0;
       int32_t idx = -1, lo = 0;
@@ -282,7 +283,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
           const uint32_t L = (uint32_t)__builtin_ctzll(am);
           uint32_t bl = rdlane(best_len, L), br = rdlane(best_ref, L);
           hc_eval_slice<HAS_DICT>(in, x, i + L, rdlane(seq, L), (int32_t)rdlane((uint32_t)idx, L),
-                                  (int32_t)rdlane((uint32_t)lo, L), rdlane(depth, L), max_depth, total, lane, bl, br);
+                                  (int32_t)rdlane((uint32_t)lo, L), rdlane(depth, L), max_depth, elimit, lane, bl, br);
           if (lane == L) {
             best_len = bl;
             best_ref = br;
@@ -311,12 +312,12 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
         m4 = m4 && lane <= W;
         uint32_t ml = 0;
         bool more = false;
-        if (m4) ml = hc_lane_len<HAS_DICT>(in, p, c, total, 64u, more);
-        hc_finish_long<HAS_DICT>(in, i, true, c, ml, more, total, lane);
+        if (m4) ml = hc_lane_len<HAS_DICT>(in, p, c, elimit, 64u, more);
+        hc_finish_long<HAS_DICT>(in, i, true, c, ml, more, elimit, lane);
         if (m4 && ml > best_len) {  // strictly longer: the nearest candidate wins ties (:137)
           best_len = ml;
           best_ref = c;
-          if (p + best_len == total) done = true;  // :140-142
+          if (p + best_len == elimit) done = true;  // :140-142
         }
         if (cnd) depth++;
       }
@@ -340,7 +341,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
       op = emit_sequence(out, op, in.src + (anchor - D), ms - anchor, im - bref, ml, lane);
       i = ms + ml;  // :173-174
       anchor = i;
-      if (i + 4 > total) break;  // :176-178
+      if (i + 4 > plimit) break;  // :176-178
       // :180-185.  Positions ms+1 .. im are inserted a second time: their buckets get a floor at
       // the lowest of them (highest positions first, so the lowest one writes last).
       for (uint32_t hi = im; hi > ms; hi -= (hi - ms < kWave ? hi - ms : kWave)) {
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t ma
       in.D = b == 0 ? a.dict_len : 65535u;
     }
     in.total = in.D + uni(block_src_len(a, b));
+    set_end_limits(in, a.conformant);
     uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;

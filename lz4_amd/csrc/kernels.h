@@ -27,6 +27,9 @@ struct BatchArgs {
   // Linked blocks (lz4_frame_encoder.dart:170-206): blocks are contiguous (src_stride == src_len_uniform)
   // and block b >= 1 takes the 65535 bytes in front of it as its dictionary; block 0 takes `dict`.
   uint32_t linked = 0;
+  // Nonzero: blocks follow the lz4 block format's end-of-block rules instead of the reference's
+  // (which ends blocks inside matches): see EncIn::plimit / elimit.
+  uint32_t conformant = 0;
 };
 
 __host__ __device__ inline uint32_t block_src_len(const BatchArgs &a, uint32_t b) {

@@ -56,6 +56,9 @@ class Lz4FrameOptions:
     compression: Lz4FrameCompression = Lz4FrameCompression.fast
     acceleration: int = 1
     hcOptions: Optional[Lz4HcOptions] = None  # noqa: N815
+    # Not a reference option: blocks follow the lz4 block format's end-of-block rules, so any
+    # LZ4 decoder (the lz4 CLI included) accepts the frame; output differs from the reference's.
+    specConformantBlocks: bool = False  # noqa: N815
 
     def __post_init__(self):
         if self.acceleration < 1:

@@ -319,8 +319,22 @@ static const uint8_t *make_input(const uint8_t *src, size_t n, const uint8_t *di
 
 /* ------------------------------------------------------ fast block encoder
  * block/lz4_block_encoder.dart:35-157. */
-static int fast_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
-                               size_t dict_len_in, int64_t acceleration) {
+/* End-of-block limits.  The reference searches up to the last four bytes and lets a match
+ * run to the very end of the block (plimit = elimit = total).  The optional spec-conformant
+ * mode (not in the reference; lz4 block format "end of block" rules) stops searching 12 bytes
+ * before the end, keeps the last 5 bytes literal and encodes blocks under 13 bytes as
+ * literals only, so that any LZ4 decoder accepts the block. */
+static void end_limits(int conformant, size_t total, size_t n, size_t *plimit, size_t *elimit) {
+  *plimit = total;
+  *elimit = total;
+  if (conformant) {
+    *plimit = n >= 13 ? total - 8 : 0;
+    *elimit = n >= 5 ? total - 5 : 0;
+  }
+}
+
+static int fast_encode_to_sink_ex(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                                  size_t dict_len_in, int64_t acceleration, int conformant) {
   if (acceleration < 1) return LZ4REF_RANGE; /* :41-43, before the empty check */
   if (n == 0) return LZ4REF_OK;              /* :45-48 */
 
@@ -345,9 +359,11 @@ static int fast_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const ui
   {
     size_t total = dict_len + n;
     size_t anchor = dict_len, i = dict_len;
+    size_t plimit, elimit;
+    end_limits(conformant, total, n, &plimit, &elimit);
     /* Dart's >> on a non-negative int yields 0 for shift counts >= 64 */
     unsigned sh = acceleration > 62 ? 63 : (unsigned)acceleration;
-    while (i + 4 <= total) { /* :95 */
+    while (i + 4 <= plimit) { /* :95 */
       uint32_t seq = rd32(in + i);
       uint32_t h = hash16(seq);
       int32_t ref = table[h];
@@ -356,11 +372,11 @@ static int fast_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const ui
         size_t ms = i, rs = (size_t)ref;
         while (ms > anchor && rs > 0 && in[ms - 1] == in[rs - 1]) { ms--; rs--; } /* :107-113 */
         size_t ml = 4;
-        while (ms + ml < total && in[ms + ml] == in[rs + ml]) ml++; /* :117-121 */
+        while (ms + ml < elimit && in[ms + ml] == in[rs + ml]) ml++; /* :117-121 */
         if ((st = emit_sequence(w, in, anchor, ms - anchor, ms - rs, ml))) goto done;
         i = ms + ml;
         anchor = i;
-        if (i + 4 > total) break; /* :135-137 */
+        if (i + 4 > plimit) break; /* :135-137 */
         for (size_t j = i - ml + 1; j + 4 <= i; j++) /* :139-145 */
           table[hash16(rd32(in + j))] = (int32_t)j;
         continue;
@@ -376,6 +392,11 @@ done:
   return st;
 }
 
+static int fast_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                               size_t dict_len_in, int64_t acceleration) {
+  return fast_encode_to_sink_ex(w, src, n, dict, dict_len_in, acceleration, 0);
+}
+
 int lz4ref_block_compress_fast(const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
                                int64_t acceleration, uint8_t *dst, size_t cap, size_t *out_len) {
   sink_t w = {dst, 0, cap, -1};
@@ -386,8 +407,8 @@ int lz4ref_block_compress_fast(const uint8_t *src, size_t n, const uint8_t *dict
 
 /* -------------------------------------------------------- HC block encoder
  * hc/lz4_hc_block_encoder.dart:49-197; options hc/lz4_hc_options.dart:10-16. */
-static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
-                             size_t dict_len_in, int64_t max_depth) {
+static int hc_encode_to_sink_ex(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                                size_t dict_len_in, int64_t max_depth, int conformant) {
   if (max_depth < 1) return LZ4REF_RANGE; /* Lz4HcOptions ctor */
   if (n == 0) return LZ4REF_OK;           /* :57-60 */
 
@@ -423,7 +444,9 @@ static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint
       for (size_t pos = 0; pos + 4 <= dict_len; pos++) HC_INSERT(pos, tmp); /* :105-109 */
 
     size_t anchor = dict_len, i = dict_len;
-    while (i + 4 <= total) { /* :116 */
+    size_t plimit, elimit;
+    end_limits(conformant, total, n, &plimit, &elimit);
+    while (i + 4 <= plimit) { /* :116 */
       int32_t cand;
       HC_INSERT(i, cand);
       size_t best_len = 0;
@@ -438,11 +461,11 @@ static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint
         }
         if (rd32(in + cand) == seq_i) { /* :131 */
           size_t ml = 4;
-          while (i + ml < total && in[i + ml] == in[(size_t)cand + ml]) ml++;
+          while (i + ml < elimit && in[i + ml] == in[(size_t)cand + ml]) ml++;
           if (ml > best_len) { /* strict: nearest wins ties */
             best_len = ml;
             best_ref = cand;
-            if (i + best_len == total) break; /* :140-142 */
+            if (i + best_len == elimit) break; /* :140-142 */
           }
         }
         cand = chain[cand];
@@ -454,7 +477,7 @@ static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint
         if ((st = emit_sequence(w, in, anchor, ms - anchor, ms - rs, al))) goto done;
         i = ms + al;
         anchor = i;
-        if (i + 4 > total) break; /* :176-178 */
+        if (i + 4 > plimit) break; /* :176-178 */
         for (size_t j = i - al + 1; j + 4 <= i; j++) HC_INSERT(j, tmp); /* :180-185 */
         continue;
       }
@@ -466,6 +489,20 @@ done:
   free(head);
   free(chain);
   free(owned);
+  return st;
+}
+
+static int hc_encode_to_sink(sink_t *w, const uint8_t *src, size_t n, const uint8_t *dict,
+                             size_t dict_len_in, int64_t max_depth) {
+  return hc_encode_to_sink_ex(w, src, n, dict, dict_len_in, max_depth, 0);
+}
+
+int lz4ref_block_compress_ex(const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len, int level,
+                             int64_t param, int conformant, uint8_t *dst, size_t cap, size_t *out_len) {
+  sink_t w = {dst, 0, cap, -1};
+  int st = level == 0 ? fast_encode_to_sink_ex(&w, src, n, dict, dict_len, param, conformant)
+                      : hc_encode_to_sink_ex(&w, src, n, dict, dict_len, param, conformant);
+  if (out_len) *out_len = w.len;
   return st;
 }
 
@@ -679,9 +716,11 @@ int lz4ref_frame_encode(const uint8_t *src, size_t n, const lz4ref_frame_options
     if ((st = sink_u32le(&w, 0))) goto fail; /* placeholder :210-211 */
     size_t payload_start = w.len;
     if (o->compression == 0)
-      st = fast_encode_to_sink(&w, chunk, chunk_len, bdict, bdict_len, o->acceleration);
+      st = fast_encode_to_sink_ex(&w, chunk, chunk_len, bdict, bdict_len, o->acceleration,
+                                  o->spec_conformant);
     else
-      st = hc_encode_to_sink(&w, chunk, chunk_len, bdict, bdict_len, o->hc_max_search_depth);
+      st = hc_encode_to_sink_ex(&w, chunk, chunk_len, bdict, bdict_len, o->hc_max_search_depth,
+                                o->spec_conformant);
     if (st) goto fail;
 
     size_t clen = w.len - payload_start;
@@ -1173,8 +1212,9 @@ static int senc_encode_block(lz4ref_stream_encoder *e, sink_t *w, const uint8_t 
   size_t start = w->len;
   if ((st = sink_u32le(w, 0))) return st;
   size_t payload = w->len;
-  st = o->compression == 0 ? fast_encode_to_sink(w, chunk, n, d, dl, o->acceleration)
-                           : hc_encode_to_sink(w, chunk, n, d, dl, o->hc_max_search_depth);
+  st = o->compression == 0
+           ? fast_encode_to_sink_ex(w, chunk, n, d, dl, o->acceleration, o->spec_conformant)
+           : hc_encode_to_sink_ex(w, chunk, n, d, dl, o->hc_max_search_depth, o->spec_conformant);
   if (st) return st;
   size_t clen = w->len - payload;
   if (clen < n) { /* :136-144 */

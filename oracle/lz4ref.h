@@ -80,6 +80,14 @@ int lz4ref_block_compress_hc(const uint8_t *src, size_t n,
                              int64_t max_search_depth,
                              uint8_t *dst, size_t cap, size_t *out_len);
 
+/* level 0 fast (param = acceleration) / 1 hc (param = maxSearchDepth); conformant != 0 applies
+ * the lz4 block format's end-of-block rules (no counterpart in the reference, which ends
+ * blocks inside matches): no match starts in the last 12 bytes, the last 5 bytes are
+ * literals, blocks under 13 bytes are literals only. */
+int lz4ref_block_compress_ex(const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
+                             int level, int64_t param, int conformant,
+                             uint8_t *dst, size_t cap, size_t *out_len);
+
 /* strict: lz4BlockDecompress (lz4_block_decoder.dart:7-77) */
 int lz4ref_block_decompress(const uint8_t *src, size_t c,
                             uint8_t *dst, int64_t decompressed_size);
@@ -116,6 +124,8 @@ typedef struct {
   int32_t hc_max_search_depth;
   uint32_t dict_id;
   uint64_t content_size;
+  int32_t spec_conformant;    /* not in the reference: blocks obey the lz4 end-of-block rules */
+  int32_t reserved;
 } lz4ref_frame_options;
 
 void lz4ref_frame_options_default(lz4ref_frame_options *o);

@@ -46,6 +46,8 @@ class FrameOptions(C.Structure):
         ("hc_max_search_depth", C.c_int32),
         ("dict_id", C.c_uint32),
         ("content_size", C.c_uint64),
+        ("spec_conformant", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -85,6 +87,9 @@ def lib():
                                                  C.c_int64, C.c_void_p, C.c_size_t,
                                                  C.POINTER(C.c_size_t)]
         L.lz4ref_block_compress_hc.argtypes = L.lz4ref_block_compress_fast.argtypes
+        L.lz4ref_block_compress_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
+                                               C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                               C.POINTER(C.c_size_t)]
         L.lz4ref_block_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64]
         L.lz4ref_block_decompress_into.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.POINTER(C.c_size_t)]
@@ -166,6 +171,23 @@ def block_compress_hc(src: bytes, dictionary=None, max_search_depth: int = 64) -
     return _compress(lib().lz4ref_block_compress_hc, src, dictionary, max_search_depth)
 
 
+def block_compress_ex(src: bytes, dictionary=None, level: int = 0, param: int | None = None,
+                      conformant: bool = False) -> bytes:
+    """Either encoder with the optional lz4-spec end-of-block rules (see lz4ref.h)."""
+    src = bytes(src)
+    if param is None:
+        param = 1 if level == 0 else 64
+    cap = compress_bound(len(src)) + 16
+    dst = C.create_string_buffer(cap)
+    out = C.c_size_t(0)
+    d = bytes(dictionary) if dictionary is not None else None
+    st = lib().lz4ref_block_compress_ex(src, len(src), d, len(d) if d is not None else 0, level, param,
+                                        int(conformant), dst, cap, C.byref(out))
+    if st:
+        _raise(st)
+    return dst.raw[: out.value]
+
+
 def block_decompress(src: bytes, decompressed_size: int) -> bytes:
     """lz4BlockDecompress (lib/src/block/lz4_block_decoder.dart:7-77)."""
     src = bytes(src)
@@ -212,7 +234,7 @@ class Xxh32:
 
 def frame_options(block_size_id=7, block_independence=True, block_checksum=False,
                   content_checksum=False, content_size=None, dict_id=None, compression=0,
-                  acceleration=1, hc_max_search_depth=64) -> FrameOptions:
+                  acceleration=1, hc_max_search_depth=64, spec_conformant=False) -> FrameOptions:
     o = FrameOptions()
     lib().lz4ref_frame_options_default(C.byref(o))
     o.block_size_id = block_size_id
@@ -226,6 +248,7 @@ def frame_options(block_size_id=7, block_independence=True, block_checksum=False
     o.compression = compression
     o.acceleration = acceleration
     o.hc_max_search_depth = hc_max_search_depth
+    o.spec_conformant = int(spec_conformant)
     return o
 
 

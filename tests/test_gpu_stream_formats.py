@@ -314,3 +314,62 @@ def test_stream_decoder_two_full_legacy_blocks(oracle):
     out, err = check_decode(oracle, frame, sizes=[1, 2, 3, 5, 8, 13, 21] * 50 + [4096])
     assert err is None and out == src
     assert lz4_amd.lz4LegacyEncode(src) == oracle.legacy_frame_encode(src)
+
+
+# ------------------------------------------------------ spec-conformant blocks
+
+def _edge_blocks():
+    """Inputs whose reference encoding ends inside a match or searches into the last bytes."""
+    rng = np.random.default_rng(5)
+    out = [b"", b"a", b"abcd" * 3, b"abcd" * 3 + b"a", b"\x41" * 13, b"\x41" * 65536,
+           bytes(i & 0x1F for i in range(70000)), mixed(65536, 90), mixed(65536 + 11, 91)]
+    tail = rng.integers(0, 256, size=40, dtype=np.uint8).tobytes()
+    for cut in range(0, 16):  # a repeated tail that the unrestricted encoder would match to the end
+        body = mixed(3000, 92) + tail + mixed(500, 93) + tail
+        out.append(body[:len(body) - cut])
+    return out
+
+
+def test_spec_conformant_frames_equal_oracle_and_decode_with_lz4_cli(oracle, tmp_path):
+    import os
+    import shutil
+    import subprocess
+    cli = shutil.which("lz4") or "/opt/conda/bin/lz4"
+    have_cli = os.path.exists(cli)
+    dictionary = mixed(70000, 94)
+    for compression in (Lz4FrameCompression.fast, Lz4FrameCompression.hc):
+        for linked in (False, True):
+            o = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockIndependence=not linked,
+                                compression=compression, contentChecksum=True, specConformantBlocks=True)
+            ro = ref_options(oracle, o)
+            ro.spec_conformant = 1
+            for k, src in enumerate(_edge_blocks() + [mixed(400000, 95)]):
+                got = lz4_amd.lz4FrameEncodeWithOptions(src, options=o)
+                assert got == oracle.frame_encode(src, ro), (compression, linked, k)
+                assert lz4_amd.lz4FrameDecode(got) == src
+                if have_cli and (k % 4 == 0 or len(src) > 100000):
+                    p = tmp_path / "f.lz4"
+                    p.write_bytes(got)
+                    out = subprocess.run([cli, "-d", "-c", str(p)], capture_output=True, check=True).stdout
+                    assert out == src
+            # with a dictionary (not checked with the CLI: it would need the dictionary file too)
+            src = dictionary[-5000:] + mixed(100000, 96)
+            od = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, blockIndependence=not linked,
+                                 compression=compression, dictId=9, specConformantBlocks=True)
+            rd = ref_options(oracle, od)
+            rd.spec_conformant = 1
+            got = lz4_amd.lz4FrameEncodeWithOptions(src, options=od, dictionary=dictionary)
+            assert got == oracle.frame_encode(src, rd, dictionary)
+            assert lz4_amd.lz4FrameDecode(got, dictionaryResolver=lambda i: dictionary) == src
+    # the stream encoder honours the option too
+    o = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, specConformantBlocks=True)
+    src = mixed(300000, 97)
+    pieces, err = run_stream(lz4_amd.lz4FrameEncoderWithOptions(options=o).bind(chunked(src, [70001])))
+    assert err is None and b"".join(pieces) == lz4_amd.lz4FrameEncodeWithOptions(src, options=o)
+
+
+def test_default_mode_unchanged_by_the_conformant_option(oracle):
+    """specConformantBlocks=False stays byte-identical to the reference-faithful oracle."""
+    for src in _edge_blocks():
+        o = Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB)
+        assert lz4_amd.lz4FrameEncodeWithOptions(src, options=o) == oracle.frame_encode(src, ref_options(oracle, o))
