@@ -101,8 +101,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # LZ4MI_BENCH_DIST=1 takes the multi-rank code path (RCCL init, size exchange) with one rank,
+    # to rehearse it on a one-GPU box under torch.distributed.run
+    multi = world > 1 or os.environ.get("LZ4MI_BENCH_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -127,7 +133,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -141,7 +147,7 @@ def main():
             _, sizes, st_c = codec.compress_blocks(src, BLOCK, acceleration=args.acceleration, out=slots)
             if record:
                 e1.record(stream)
-            if world > 1:  # record sizes of every rank -> absolute frame offsets of this rank's blocks
+            if multi:  # record sizes of every rank -> absolute frame offsets of this rank's blocks
                 rec = torch.where(sizes < BLOCK, sizes, torch.full_like(sizes, BLOCK)) + 4
                 frame_offsets_uniform(rec, 7)
             _, out_len, st_d = codec.decompress_blocks(slots, sizes, BLOCK, comp_stride=stride, strict=True, out=out)
@@ -159,7 +165,7 @@ def main():
         sizes, st_c, st_d = step(True)
     barrier()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([wall], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -170,8 +176,7 @@ def main():
     total_c = int(sizes.to(torch.int64).sum())
 
     if rank == 0:
-        enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["enc"]])) if world == 1 else \
-            float(np.mean([a.elapsed_time(b) for a, b in ev["enc"]]))
+        enc_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["enc"]]))
         dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev["dec"]]))
         n_bytes = nb * BLOCK
         gb = n_bytes / 1e9
@@ -208,7 +213,7 @@ def main():
                             "fast compress (acceleration=%d) + strict decompress round trip" % args.acceleration,
                 "blocks_per_gpu": nb, "block_bytes": BLOCK, "corpus_bytes_per_gpu": n_bytes,
                 "compressed_bytes_rank0": total_c, "ratio": total_c / n_bytes,
-                "exchange": "none" if world == 1 else "RCCL all-gather of int32 record sizes + prefix sum",
+                "exchange": "RCCL all-gather of int32 record sizes + prefix sum" if multi else "none",
             },
             "compress_GBps_per_gpu": kernels["encode_fast_kernel"]["GBps_uncompressed"],
             "decompress_GBps_per_gpu": kernels["decode_kernel"]["GBps_uncompressed"],
@@ -228,7 +233,7 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
