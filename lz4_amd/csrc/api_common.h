@@ -60,6 +60,8 @@ struct lz4mi_ctx {
       hashes, words, total;
   // HC encoder: per-slot position index (rank + sorted), bucket counters and floors
   lz4mi::DevBuf hc_chain, hc_cnt, hc_floor;
+  // decoder: blocks handed from the plain kernel to the group kernel (16 bytes per block)
+  lz4mi::DevBuf redo;
 
   // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
   uint32_t shard_blocks = 0;

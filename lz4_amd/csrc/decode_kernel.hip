@@ -17,6 +17,8 @@
 // compiler's wait insertion never adds a drain of its own to the load-free paths.
 // Long runs go memory to memory with 16-byte aligned stores (1 KiB per wave-instruction);
 // matches that overlap their own output replicate the period with a modulo gather.
+// Blocks that consist of short sequences (text-like data: ten bytes per sequence) are put down
+// by the first kernel and finished by a second one that decodes about ten sequences per step.
 #include "device_common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -150,6 +152,38 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   vm_quiesce();
 }
 
+// Inclusive prefix sum over the 64 lanes: row shifts inside the 16-lane rows, then the two row
+// broadcasts (lanes without a source add zero).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t from) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v);
+}
+
+#ifndef LZ4MI_MS_ENTER
+#define LZ4MI_MS_ENTER 48
+#endif
+#ifndef LZ4MI_MS_MIN
+#define LZ4MI_MS_MIN 3
+#endif
+constexpr uint32_t kMsEnter = LZ4MI_MS_ENTER;  // short sequences in a row before the first kernel puts a block down
+constexpr uint32_t kMsPenalty = 8;             // what a sequence with a length extension takes off the score
+constexpr uint32_t kMsReenter = 4;             // the same inside the second kernel, where changing loops is cheap
+constexpr uint32_t kMsTry = 1;                 // GROUPS: short sequences in a row before the next try
+constexpr uint32_t kMsLeave = 16;              // GROUPS: single sequences in a row before handing back
+constexpr uint32_t kMsMin = LZ4MI_MS_MIN;      // smallest group worth giving up the ring for
+
 #ifndef LZ4MI_RING
 #define LZ4MI_RING 8192
 #endif
@@ -161,11 +195,21 @@ constexpr uint32_t kShort = 256;   // copies up to this length go through the ri
 // (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
 // non-negative positions come from dst itself (earlier blocks of a linked frame),
 // negative positions from the tail of `prefix` (dictionary).  out_len = bytes written.
-template <bool STRICT, bool HAS_PREFIX>
-__device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
-                                                const uint64_t op_start, uint32_t cap, uint32_t back_limit,
-                                                const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                                lds_u8 *ring, uint32_t lane, uint32_t &out_len) {
+//
+// The loop exists in two variants that hand a block back and forth at sequence boundaries, each
+// starting from fresh window/ring state as if the rest of the block were a block of its own:
+// GROUPS == false takes one sequence per iteration and, when HANDOVER is nonzero, returns
+// kSwitchRun once its short-sequence score (+1 for a sequence without length extensions,
+// -kMsPenalty for any other) reaches HANDOVER; GROUPS == true tries whole groups of short
+// sequences first (see below) and returns kSwitchRun once kMsLeave sequences in a row had to go
+// one by one.  (With the group code inside the only loop of the only kernel, long-match data
+// decoded 5-9 % slower; the first kernel of a launch therefore contains the plain loop alone.)
+constexpr int32_t kSwitchRun = -1;  // not a status: continue with the other variant at in_used / out_len
+template <bool STRICT, bool HAS_PREFIX, bool GROUPS, uint32_t HANDOVER>
+__device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
+                                              const uint64_t op_start, uint32_t cap, uint32_t back_limit,
+                                              const uint8_t *__restrict__ prefix, uint32_t prefix_len,
+                                              lds_u8 *ring, uint32_t lane, uint32_t &in_used, uint32_t &out_len) {
   InWindow w;
   w.mis = (uint32_t)((uintptr_t)src & 3u);
   w.al = src - w.mis;
@@ -178,6 +222,8 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 
   uint32_t ip = 0, op = 0;  // op counts bytes written by this block
   uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
+  uint32_t shorts = 0;      // score: +1 per sequence without length extensions, -kMsPenalty per other one
+  uint32_t idle = 0;        // GROUPS: sequences taken one by one since the last group
   const uint32_t in_end = src_len;
   int32_t st = LZ4MI_OK;
   uint8_t *const out = dst + op_start;
@@ -193,8 +239,10 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     } else {
       if (ip >= in_end) break;  // :86-88
     }
+    if (!GROUPS && HANDOVER && shorts >= HANDOVER) { st = kSwitchRun; break; }
     uint32_t token = sbyte(w, sm, ip, lane);
     ip++;
+    const bool shortseq = (token & 0xF0u) != 0xF0u && (token & 15u) != 15u;  // no length extensions
     uint64_t lit64 = token >> 4;
     if (lit64 == 15) {
       if (!read_ext(w, sm, ip, in_end, lit64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
@@ -307,34 +355,231 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       PH(5); PH_CNT(13);
     }
     op += ml;
+    shorts = shortseq ? shorts + 1u : (shorts > kMsPenalty ? shorts - kMsPenalty : 0u);
+    if (!GROUPS) continue;  // (the hand-over test sits at the top, behind the end-of-block checks)
+    if (++idle > kMsLeave && ip < in_end && op < cap) { st = kSwitchRun; break; }
+    while (shorts >= kMsTry && ip < in_end && op < cap) {  // else the checks at the top decide
+      // ---- several short sequences at once.  Data made of short sequences (text) spends its time
+      // on per-sequence latency, above all the load of a match source that is older than the ring.
+      // Here every lane parses the byte it holds as if it were a token; following the chain of
+      // real token starts from lane 0 is a handful of scalar steps; a prefix sum places every
+      // sequence in the output; then all literal bytes of the group go out in one store, all match
+      // sources are fetched with one round trip and all matches are written together.  A sequence
+      // joins the group only if it has no length extension, is not the last of the block, passes
+      // the reference's checks, and its source lies wholly in output written before the group
+      // (18 bytes from the source start, so the fixed-size fetch never reads ahead of the data);
+      // the first sequence that does not qualify ends the group and goes through the general path.
+      if (sm.sp != ip) stream_load(w, sm, ip, lane);
+      const uint32_t avail_in = in_end - ip;
+      const uint32_t ll = sm.S >> 4, ml = (sm.S & 15u) + 4u;
+      const uint32_t nx = lane + 3u + ll;  // where the next token would start
+      const uint32_t off = lane_pull(sm.S, lane + 1u + ll) | (lane_pull(sm.S, lane + 2u + ll) << 8);
+      const bool ok = ll < 15u && ml < 19u && nx <= kWave && nx < avail_in && off != 0u;
+      const uint64_t okm = ballot(ok);
+      uint64_t starts = 0;
+      uint32_t r = 0;
+      while (r < kWave && ((okm >> r) & 1ull)) {
+        starts |= 1ull << r;
+        r = rdlane(nx, r);
+      }
+      if (starts) {
+        bool is_start = (starts >> lane) & 1ull;
+        const uint32_t mine = is_start ? ll + ml : 0u;
+        const uint32_t incl = wave_incl_scan(mine);
+        const uint32_t excl = incl - mine;
+        const uint32_t mrel = excl + ll;  // match position relative to op
+        const int64_t srcpos = (int64_t)op_start + op + mrel - off;
+        const bool bad = is_start && ((uint64_t)off > (uint64_t)op + mrel + back_limit ||  // copyMatch's distance check
+                                      off < mrel + 18u || srcpos < 0);
+        const uint64_t bm = ballot(bad);
+        uint32_t total = rdlane(incl, kWave - 1);
+        if (bm) {
+          const uint32_t v = (uint32_t)__builtin_ctzll(bm);
+          starts &= (1ull << v) - 1ull;
+          r = v;
+          total = rdlane(excl, v);
+          is_start = (starts >> lane) & 1ull;
+        }
+        if ((uint32_t)__builtin_popcountll(starts) >= kMsMin && total <= cap - op) {
+          uint64_t v0 = 0, v1 = 0;
+          uint32_t v2 = 0;
+          if (is_start) {  // sources first: they queue behind the previous group's stores only
+            const uint8_t *sp8 = dst + srcpos;
+            v0 = ld64(sp8);
+            v1 = ld64(sp8 + 8);
+            v2 = ld16(sp8 + 16);
+          }
+          {  // every literal byte of the group: lane j belongs to the nearest start at or below it
+            const uint64_t below = starts & (~0ull >> (63u - lane));
+            const uint32_t k = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+            const uint32_t llk = lane_pull(ll, k), exk = lane_pull(excl, k);
+            const uint32_t li = lane - k - 1u;
+            if (lane < r && li < llk) out[op + exk + li] = (uint8_t)sm.S;
+          }
+          if (is_start) {
+            uint8_t *d = out + op + mrel;
+            if (ml >= 16u) {
+              st64(d, v0);
+              st64(d + 8, v1);
+              if (ml == 18u) st16(d + 16, v2);
+              if (ml == 17u) d[16] = (uint8_t)v2;
+            } else {
+              uint64_t cur = v0;
+              if (ml & 8u) { st64(d, v0); d += 8; cur = v1; }
+              if (ml & 4u) { st32(d, (uint32_t)cur); d += 4; cur >>= 32; }
+              if (ml & 2u) { st16(d, (uint32_t)cur); d += 2; cur >>= 16; }
+              if (ml & 1u) d[0] = (uint8_t)cur;
+            }
+          }
+          ip += r;
+          op += total;
+          rlo = op;  // the ring holds nothing of this group
+          idle = 0;
+          continue;
+        }
+      }
+      shorts = 0;
+    }
   }
   PH(0);
   PH_FLUSH(g_dec_phase, lane);
+  in_used = ip;
   out_len = op;
   return st;
 }
 
+template <bool STRICT, bool HAS_PREFIX, bool ALLOW_GROUPS>
+__device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
+                                                const uint64_t op_start, uint32_t cap, uint32_t back_limit,
+                                                const uint8_t *__restrict__ prefix, uint32_t prefix_len,
+                                                lds_u8 *ring, uint32_t lane, uint32_t &out_len) {
+  if (!ALLOW_GROUPS) {  // the plain loop alone, start to end
+    uint32_t used = 0;
+    return decode_run<STRICT, HAS_PREFIX, false, 0>(src, src_len, dst, op_start, cap, back_limit, prefix,
+                                                        prefix_len, ring, lane, used, out_len);
+  }
+  uint32_t ip = 0, op = 0;
+  int32_t st;
+  for (bool groups = true;; groups = !groups) {  // callers come here because short sequences were seen
+    uint32_t di = 0, dn = 0;
+    st = groups ? decode_run<STRICT, HAS_PREFIX, true, 1>(src + ip, src_len - ip, dst, op_start + op, cap - op,
+                                                              back_limit + op, prefix, prefix_len, ring, lane, di, dn)
+                : decode_run<STRICT, HAS_PREFIX, false, kMsReenter>(src + ip, src_len - ip, dst, op_start + op, cap - op,
+                                                               back_limit + op, prefix, prefix_len, ring, lane, di,
+                                                               dn);
+    ip += di;
+    op += dn;
+    if (st != kSwitchRun) break;
+  }
+  out_len = op;
+  return st;
+}
+
+// A launch is two kernels on the stream.  decode_kernel takes every block through the plain
+// loop; a block that turns out to consist of short sequences is put down at the sequence boundary
+// it has reached (block index, bytes consumed, bytes produced go into the redo list) and the
+// wavefront moves on.  decode_redo_kernel then finishes the listed blocks with the group variant.
+// Long-match data never pays for the group code (it is not in the first kernel at all); when the
+// list stays empty the second kernel returns at once.
+struct RedoEntry { uint32_t block, in_used, out_len, pad; };
+
+// In the second kernel the launch arguments are not held in registers across a block: its loops
+// keep their control state in scalar registers and need nearly all of them (holding the
+// arguments too made the compiler spill scalars in the sequence loop).  They are read again
+// from the kernel argument segment (BatchArgs first, then the other arguments in order).
+struct DecodeKArgs {
+  BatchArgs a;
+  uint32_t *counter;
+  uint32_t *redo_count;
+  RedoEntry *redo;
+};
+typedef const volatile __attribute__((address_space(4))) DecodeKArgs *DecodeKArgsPtr;
+
+struct BlockIo {
+  const uint8_t *src;
+  uint32_t src_len;
+  uint8_t *dst;
+  uint32_t cap;
+};
+__device__ __forceinline__ BlockIo block_io(DecodeKArgsPtr ka, uint32_t b) {
+  BlockIo io;
+  const uint64_t *src_off = ka->a.src_off, *dst_off = ka->a.dst_off;
+  const uint32_t *src_len_v = ka->a.src_len, *dst_cap = ka->a.dst_cap;
+  io.src = ka->a.src + uni64(src_off ? src_off[b] : (uint64_t)b * ka->a.src_stride);
+  if (src_len_v) {
+    io.src_len = uni(src_len_v[b]);
+  } else {
+    const uint32_t u = ka->a.src_len_uniform;
+    const uint64_t start = (uint64_t)b * u, tot = ka->a.src_total;
+    const uint64_t left = tot > start ? tot - start : 0;
+    io.src_len = left < u ? (uint32_t)left : u;
+  }
+  io.dst = ka->a.dst + uni64(dst_off ? dst_off[b] : (uint64_t)b * ka->a.dst_stride);
+  io.cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
+  return io;
+}
+
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter) {
+__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter, uint32_t *redo_count,
+                                                     RedoEntry *redo) {
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
   const uint32_t lane = lane_id();
   lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
-  uint32_t prefix_len = a.dict_len;
-  for (;;) {
-    const uint32_t b = next_block(counter, lane);
+  const uint32_t prefix_len = a.dict_len;
+  // When the launch has a wavefront for every block, a wavefront's block is its own index (thousands
+  // of wavefronts starting at once would otherwise serialise on the queue head); larger batches
+  // are handed out through the queue.
+  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+  const bool direct = a.nblocks <= nwaves;
+  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
+  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
-    uint32_t src_len = uni(block_src_len(a, b));
+    const uint32_t src_len = uni(block_src_len(a, b));
     uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
-    uint32_t out_len = 0;
-    int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, ring,
-                                                  lane, out_len);
+    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t used = 0, out_len = 0;
+    const int32_t st = decode_run<STRICT, HAS_PREFIX, false, kMsEnter>(src, src_len, dst, 0, cap, prefix_len, prefix,
+                                                                   prefix_len, ring, lane, used, out_len);
     if (lane == 0) {
-      a.out_len[b] = out_len;
-      a.status[b] = st;
+      if (st == kSwitchRun) {
+        const uint32_t k = atomicAdd(redo_count, 1u);
+        RedoEntry e = {b, used, out_len, 0u};
+        redo[k] = e;
+      } else {
+        a.out_len[b] = out_len;
+        a.status[b] = st;
+      }
+    }
+  }
+}
+
+template <bool STRICT, bool HAS_PREFIX>
+__global__ __launch_bounds__(256) void decode_redo_kernel(BatchArgs, uint32_t *, uint32_t *, RedoEntry *) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
+  const uint32_t lane = lane_id();
+  lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
+  DecodeKArgsPtr ka = (DecodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  const uint32_t nredo = *ka->redo_count;
+  if (nredo == 0) return;
+  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+  const bool direct = nredo <= nwaves;
+  uint32_t k = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave)
+                      : next_block(ka->counter + 1, lane);  // the second kernel's own queue head
+  for (;; k = direct ? 0xffffffffu : next_block(ka->counter + 1, lane)) {
+    if (k >= nredo) break;
+    const uint32_t b = uni(ka->redo[k].block), ip = uni(ka->redo[k].in_used), op = uni(ka->redo[k].out_len);
+    const BlockIo io = block_io(ka, b);
+    const uint8_t *prefix = ka->a.dict;
+    const uint32_t prefix_len = ka->a.dict_len;
+    uint32_t more = 0;
+    const int32_t st = decode_block<STRICT, HAS_PREFIX, true>(io.src + ip, io.src_len - ip, io.dst, op, io.cap - op,
+                                                              prefix_len + op, prefix, prefix_len, ring, lane, more);
+    if (lane == 0) {
+      ka->a.out_len[b] = op + more;
+      ka->a.status[b] = st;
     }
   }
 }
@@ -360,7 +605,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, ring, lane,
+      st = decode_block<false, true, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, ring, lane,
                                      produced);
     }
     if (lane == 0) {
@@ -391,15 +636,27 @@ void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
   hipLaunchKernelGGL(decode_chain_kernel, dim3(1), dim3(64), 0, s, c);
 }
 
-void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t grid, hipStream_t s) {
+void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *redo_count, void *redo,
+                   uint32_t grid, hipStream_t s) {
   dim3 g(grid), blk(256);
-  bool pre = a.dict_len != 0;
+  RedoEntry *r = (RedoEntry *)redo;
+  const bool pre = a.dict_len != 0;
   if (strict) {
-    if (pre) hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter);
-    else hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter);
+    if (pre) {
+      hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_redo_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r);
+    } else {
+      hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_redo_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r);
+    }
   } else {
-    if (pre) hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter);
-    else hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter);
+    if (pre) {
+      hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_redo_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r);
+    } else {
+      hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_redo_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r);
+    }
   }
 }
 

@@ -44,12 +44,17 @@ __device__ __forceinline__ uint32_t next_block(uint32_t *counter, uint32_t lane)
 }
 
 // Unaligned little-endian accesses (gfx950 global memory handles any byte alignment).
+struct __attribute__((packed)) U16U { uint16_t v; };
 struct __attribute__((packed)) U32U { uint32_t v; };
 struct __attribute__((packed)) U64U { uint64_t v; };
 struct __attribute__((packed)) U128U { uint32_t a, b, c, d; };
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t *p) { return ((const U32U *)p)->v; }
 __device__ __forceinline__ uint64_t ld64(const uint8_t *p) { return ((const U64U *)p)->v; }
+__device__ __forceinline__ uint32_t ld16(const uint8_t *p) { return ((const U16U *)p)->v; }
+__device__ __forceinline__ void st16(uint8_t *p, uint32_t v) { ((U16U *)p)->v = (uint16_t)v; }
+__device__ __forceinline__ void st32(uint8_t *p, uint32_t v) { ((U32U *)p)->v = v; }
+__device__ __forceinline__ void st64(uint8_t *p, uint64_t v) { ((U64U *)p)->v = v; }
 __device__ __forceinline__ U128U ld128(const uint8_t *p) { return *(const U128U *)p; }
 __device__ __forceinline__ void st128(uint8_t *p, U128U v) { *(U128U *)p = v; }
 

@@ -435,7 +435,7 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   sc.floor_ = c->hc_floor.as<uint32_t>();
   sc.index = c->hc_chain.as<uint32_t>();
   sc.stride = stride;
-  uint32_t *counter = c->d_counters + 2;
+  uint32_t *counter = c->d_counters + 5;  // word 5: HC queue head (0-2 decode, 4 fast encode)
   LZ4MI_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
   uint32_t grid = (a.nblocks + 3) / 4;
   if (grid > slots / 4) grid = slots / 4;
