@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile set: bench JSON, rocprofv3 kernel stats, and PMC traffic in two separate passes
+# (FETCH_SIZE and WRITE_SIZE do not fit one pass).  Run on the GPU box from the repo root;
+# results land in gpurun_out/profiles_new/ for copying into profiles/.
+set -e
+out=gpurun_out/profiles_new
+rm -rf $out && mkdir -p $out
+export TMPDIR=/tmp
+timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -f csv -- python bench.py --no-cpu-baseline --steps 12 --warmup 1 > $out/trace.log 2>&1
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f -f csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w -f csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/pmc_write.log 2>&1
+cp $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $out/pmc_fetch.csv
+cp $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_write.csv
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+ls -la $out

@@ -190,6 +190,56 @@ def test_block_decoder_fuzz_status_parity(codec, oracle):
     assert N.OK == 0
 
 
+def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle):
+    """Blocks made of thousands of short sequences (text through the HC encoder) take the
+    decoder's second kernel, which decodes groups of sequences per step: status and bytes
+    against the oracle for intact and damaged blocks, strict and lenient, with and without a
+    dictionary prefix, full-size and ragged blocks, reference-style and spec-conformant ends."""
+    import torch
+    rng = np.random.default_rng(2024)
+    dictionary = corpus_block(3 + 8 * 50).tobytes()[:40000]
+    for use_dict in (False, True):
+        base = []
+        for i, (cls, n) in enumerate([(3, 65536), (7, 65536), (3, 70001), (4, 33333), (7, 9000), (3, 700)]):
+            data = (corpus_block(cls + 8 * i).tobytes() + corpus_block(cls + 8 * (i + 9)).tobytes())[:n]
+            d = dictionary if use_dict else None
+            base.append((oracle.block_compress_hc(data, d, 16), n))
+            base.append((oracle.block_compress_ex(data, d, level=1, param=4, conformant=True), n))
+        cases = [(s, max(0, z)) for s, z in _mutations(rng, base, 10)]
+        offs, blob = [], bytearray()
+        for s, _ in cases:
+            offs.append(len(blob))
+            blob += s
+        blob += bytes(64)
+        comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+        sizes = torch.tensor([len(s) for s, _ in cases], dtype=torch.int32, device="cuda")
+        offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        expected = torch.tensor([z for _, z in cases], dtype=torch.int32, device="cuda")
+        dict_t = torch.tensor(np.frombuffer(dictionary, dtype=np.uint8).copy(), device="cuda") if use_dict else None
+        slot = 70016
+        for strict in ((False,) if use_dict else (True, False)):  # the strict decoder takes no prefix
+            out, out_len, status = codec.decompress_blocks(comp, sizes, slot, comp_offsets=offsets, expected=expected,
+                                                           strict=strict, dictionary=dict_t)
+            out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+            n_ok = 0
+            for k, (s, z) in enumerate(cases):
+                try:
+                    if strict:
+                        ref = oracle.block_decompress(s, z)
+                    else:
+                        pre = dictionary if use_dict else b""
+                        ref = oracle.block_decompress_into(s, pre, len(pre) + z)[len(pre):]
+                    ref_status = 0
+                except oracle.Lz4RefError as e:
+                    ref, ref_status = None, e.status
+                assert int(status[k]) == ref_status, (use_dict, strict, k, z, len(s))
+                if ref is not None:
+                    n_ok += 1
+                    assert int(out_len[k]) == len(ref)
+                    assert out[k, : len(ref)].tobytes() == ref, (use_dict, strict, k)
+            assert n_ok >= 12
+
+
 # --------------------------------------------------------------- encoder
 
 def test_encoder_byte_known_answers(lz):
