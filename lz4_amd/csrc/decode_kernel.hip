@@ -172,14 +172,15 @@ __device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t from) {
 }
 
 #ifndef LZ4MI_MS_ENTER
-#define LZ4MI_MS_ENTER 48
+#define LZ4MI_MS_ENTER 64
 #endif
 #ifndef LZ4MI_MS_MIN
 #define LZ4MI_MS_MIN 3
 #endif
 constexpr uint32_t kMsEnter = LZ4MI_MS_ENTER;  // short sequences in a row before the first kernel puts a block down
+constexpr uint32_t kMsBytes = 20;              // output bytes per sequence below which a block counts as short-sequence
 constexpr uint32_t kMsPenalty = 8;             // what a sequence with a length extension takes off the score
-constexpr uint32_t kMsReenter = 4;             // the same inside the second kernel, where changing loops is cheap
+constexpr uint32_t kMsReenter = 8;             // the same inside the second kernel, where changing loops is cheap
 constexpr uint32_t kMsTry = 1;                 // GROUPS: short sequences in a row before the next try
 constexpr uint32_t kMsLeave = 16;              // GROUPS: single sequences in a row before handing back
 constexpr uint32_t kMsMin = LZ4MI_MS_MIN;      // smallest group worth giving up the ring for
@@ -222,6 +223,7 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 
   uint32_t ip = 0, op = 0;  // op counts bytes written by this block
   uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
+  uint32_t nseq = 0, mark = 0;  // plain loop with HANDOVER: sequences seen, op at the last check
   uint32_t shorts = 0;      // score: +1 per sequence without length extensions, -kMsPenalty per other one
   uint32_t idle = 0;        // GROUPS: sequences taken one by one since the last group
   const uint32_t in_end = src_len;
@@ -239,7 +241,14 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
     } else {
       if (ip >= in_end) break;  // :86-88
     }
-    if (!GROUPS && HANDOVER && shorts >= HANDOVER) { st = kSwitchRun; break; }
+    if (!GROUPS && HANDOVER) {
+      // every HANDOVER (a power of two) sequences: fewer than kMsBytes output bytes per sequence
+      // over that stretch means short sequences
+      if ((++nseq & (HANDOVER - 1u)) == 0u) {
+        if (op - mark < HANDOVER * kMsBytes) { st = kSwitchRun; break; }
+        mark = op;
+      }
+    }
     uint32_t token = sbyte(w, sm, ip, lane);
     ip++;
     const bool shortseq = (token & 0xF0u) != 0xF0u && (token & 15u) != 15u;  // no length extensions
@@ -355,8 +364,8 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
       PH(5); PH_CNT(13);
     }
     op += ml;
+    if (!GROUPS) continue;
     shorts = shortseq ? shorts + 1u : (shorts > kMsPenalty ? shorts - kMsPenalty : 0u);
-    if (!GROUPS) continue;  // (the hand-over test sits at the top, behind the end-of-block checks)
     if (++idle > kMsLeave && ip < in_end && op < cap) { st = kSwitchRun; break; }
     while (shorts >= kMsTry && ip < in_end && op < cap) {  // else the checks at the top decide
       // ---- several short sequences at once.  Data made of short sequences (text) spends its time
