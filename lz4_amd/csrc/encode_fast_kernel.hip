@@ -486,8 +486,11 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
   EncIn in;
   in.dict = a.dict;
   in.D = a.dict_len;
-  for (;;) {
-    const uint32_t b = next_block(counter, lane);
+  // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
+  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+  const bool direct = a.nblocks <= nwaves;
+  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
+  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     if (++gen > kGenMax) {  // generation wrapped: clear the slot
       for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(T + k) = make_uint4(0, 0, 0, 0);

@@ -384,8 +384,11 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t ma
   EncIn in;
   in.dict = a.dict;
   in.D = HAS_DICT ? a.dict_len : 0u;
-  for (;;) {
-    const uint32_t b = next_block(counter, lane);
+  // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
+  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+  const bool direct = a.nblocks <= nwaves;
+  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
+  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
     if (LINKED) {  // lz4_frame_encoder.dart:176-180; the encoder keeps the last 65535 bytes (:62-72)
