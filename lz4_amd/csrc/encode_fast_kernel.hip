@@ -457,20 +457,33 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   return LZ4MI_OK;
 }
 
+// The launch arguments as they lie in the kernel argument segment.  The block loop keeps its
+// control state in scalar registers and needs nearly all of them; holding the arguments there too
+// made the compiler spill scalars inside the sequence loop, so they are read again from the
+// segment at the few places that need them.
+struct EncodeKArgs {
+  BatchArgs a;
+  uint32_t sh;
+  EncodeScratch sc;
+  uint32_t *counter;
+};
+typedef const volatile __attribute__((address_space(4))) EncodeKArgs *EncodeKArgsPtr;
+
 template <bool HAS_DICT, bool LINKED>
-__global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t sh, EncodeScratch sc,
-                                                          uint32_t *counter) {
+__global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[4][kClaimSlots];
+  EncodeKArgsPtr ka = (EncodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + wave);
 #ifdef LZ4MI_PROFILE
   const unsigned long long life0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  uint32_t *T = sc.tables + (size_t)slot * kHashEntries;
-  uint32_t gen = uni(sc.slot_gen[slot]);
+  uint32_t *T = ka->sc.tables + (size_t)slot * kHashEntries;
+  uint32_t gen = uni(ka->sc.slot_gen[slot]);
   for (uint32_t k = lane; k < kClaimSlots; k += kWave) s_claim[wave][k] = 0;
+  const uint32_t sh = ka->sh;
 
   // probe schedule: offA = off(lane), offB = off(lane + kFirst)
   uint32_t offA = 0, offB = 0;
@@ -483,37 +496,49 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs a, uint32_t 
     }
   }
 
-  EncIn in;
-  in.dict = a.dict;
-  in.D = a.dict_len;
   // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
-  const bool direct = a.nblocks <= nwaves;
-  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
-  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
-    if (b >= a.nblocks) break;
+  const bool direct = ka->a.nblocks <= nwaves;
+  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(ka->counter, lane);
+  for (;; b = direct ? 0xffffffffu : next_block(ka->counter, lane)) {
+    if (b >= ka->a.nblocks) break;
     if (++gen > kGenMax) {  // generation wrapped: clear the slot
       for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(T + k) = make_uint4(0, 0, 0, 0);
       gen = 1;
     }
-    in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    EncIn in;
+    in.dict = ka->a.dict;
+    in.D = ka->a.dict_len;
+    const uint64_t *src_off = ka->a.src_off, *dst_off = ka->a.dst_off;
+    const uint32_t *src_len_v = ka->a.src_len, *dst_cap = ka->a.dst_cap;
+    in.src = ka->a.src + uni64(src_off ? src_off[b] : (uint64_t)b * ka->a.src_stride);
     if (LINKED) {  // lz4_frame_encoder.dart:176-180; the encoder keeps the last 65535 bytes (:50-61)
-      in.dict = b == 0 ? a.dict : in.src - 65535;
-      in.D = b == 0 ? a.dict_len : 65535u;
+      in.dict = b == 0 ? in.dict : in.src - 65535;
+      in.D = b == 0 ? in.D : 65535u;
     }
-    in.total = in.D + uni(block_src_len(a, b));
-    set_end_limits(in, a.conformant);
-    uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t n;
+    if (src_len_v) {
+      n = uni(src_len_v[b]);
+    } else {
+      const uint32_t u = ka->a.src_len_uniform;
+      const uint64_t start = (uint64_t)b * u, tot = ka->a.src_total;
+      const uint64_t left = tot > start ? tot - start : 0;
+      n = left < u ? (uint32_t)left : u;
+    }
+    in.total = in.D + n;
+    set_end_limits(in, ka->a.conformant);
+    uint8_t *out = ka->a.dst + uni64(dst_off ? dst_off[b] : (uint64_t)b * ka->a.dst_stride);
+    const uint32_t cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
+    const uint32_t *dictT = ka->sc.dict_table;
     uint32_t out_len = 0;
-    int32_t st = encode_block_fast<HAS_DICT, LINKED>(in, out, cap, sh, T, sc.dict_table, gen, offA, offB, (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane,
-                                             out_len);
+    int32_t st = encode_block_fast<HAS_DICT, LINKED>(in, out, cap, sh, T, dictT, gen, offA, offB,
+                                                     (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane, out_len);
     if (lane == 0) {
-      a.out_len[b] = out_len;
-      a.status[b] = st;
+      ka->a.out_len[b] = out_len;
+      ka->a.status[b] = st;
     }
   }
-  if (lane == 0) sc.slot_gen[slot] = gen;
+  if (lane == 0) ka->sc.slot_gen[slot] = gen;
 #ifdef LZ4MI_PROFILE
   if (lane == 0) atomicMax(&g_enc_phase[13], __builtin_amdgcn_s_memrealtime() - life0);
 #endif

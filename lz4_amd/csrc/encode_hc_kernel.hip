@@ -371,40 +371,63 @@ struct HcScratch {
   uint64_t stride;     // positions per slot
 };
 
+// The launch arguments as they lie in the kernel argument segment; read from there where needed
+// instead of being held in scalar registers across a block (the search loops need those).
+struct HcKArgs {
+  BatchArgs a;
+  uint32_t max_depth;
+  HcScratch sc;
+  uint32_t *counter;
+};
+typedef const volatile __attribute__((address_space(4))) HcKArgs *HcKArgsPtr;
+
 template <bool HAS_DICT, bool LINKED>
-__global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs a, uint32_t max_depth, HcScratch sc,
-                                                        uint32_t *counter) {
+__global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcScratch, uint32_t *) {
+  HcKArgsPtr ka = (HcKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  const uint64_t stride = ka->sc.stride;
   HcIndex x;
-  x.cnt = sc.cnt + (size_t)slot * kHashEntries;
-  x.floor_ = sc.floor_ + (size_t)slot * kHashEntries;
-  x.rank = sc.index + (size_t)slot * 2 * sc.stride;
-  x.sorted = x.rank + sc.stride;
-  EncIn in;
-  in.dict = a.dict;
-  in.D = HAS_DICT ? a.dict_len : 0u;
+  x.cnt = ka->sc.cnt + (size_t)slot * kHashEntries;
+  x.floor_ = ka->sc.floor_ + (size_t)slot * kHashEntries;
+  x.rank = ka->sc.index + (size_t)slot * 2 * stride;
+  x.sorted = x.rank + stride;
+  const uint32_t max_depth = ka->max_depth;
   // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
-  const bool direct = a.nblocks <= nwaves;
-  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
-  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
-    if (b >= a.nblocks) break;
-    in.src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+  const bool direct = ka->a.nblocks <= nwaves;
+  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(ka->counter, lane);
+  for (;; b = direct ? 0xffffffffu : next_block(ka->counter, lane)) {
+    if (b >= ka->a.nblocks) break;
+    EncIn in;
+    in.dict = ka->a.dict;
+    in.D = HAS_DICT ? ka->a.dict_len : 0u;
+    const uint64_t *src_off = ka->a.src_off, *dst_off = ka->a.dst_off;
+    const uint32_t *src_len_v = ka->a.src_len, *dst_cap = ka->a.dst_cap;
+    in.src = ka->a.src + uni64(src_off ? src_off[b] : (uint64_t)b * ka->a.src_stride);
     if (LINKED) {  // lz4_frame_encoder.dart:176-180; the encoder keeps the last 65535 bytes (:62-72)
-      in.dict = b == 0 ? a.dict : in.src - 65535;
-      in.D = b == 0 ? a.dict_len : 65535u;
+      in.dict = b == 0 ? in.dict : in.src - 65535;
+      in.D = b == 0 ? ka->a.dict_len : 65535u;
     }
-    in.total = in.D + uni(block_src_len(a, b));
-    set_end_limits(in, a.conformant);
-    uint8_t *out = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t n;
+    if (src_len_v) {
+      n = uni(src_len_v[b]);
+    } else {
+      const uint32_t u = ka->a.src_len_uniform;
+      const uint64_t start = (uint64_t)b * u, tot = ka->a.src_total;
+      const uint64_t left = tot > start ? tot - start : 0;
+      n = left < u ? (uint32_t)left : u;
+    }
+    in.total = in.D + n;
+    set_end_limits(in, ka->a.conformant);
+    uint8_t *out = ka->a.dst + uni64(dst_off ? dst_off[b] : (uint64_t)b * ka->a.dst_stride);
+    const uint32_t cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
     uint32_t out_len = 0;
-    int32_t st = (uint64_t)in.total > sc.stride ? (int32_t)LZ4MI_UNSUPPORTED_HERE
-                                                : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, x, lane, out_len);
+    int32_t st = (uint64_t)in.total > stride ? (int32_t)LZ4MI_UNSUPPORTED_HERE
+                                             : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, x, lane, out_len);
     if (lane == 0) {
-      a.out_len[b] = out_len;
-      a.status[b] = st;
+      ka->a.out_len[b] = out_len;
+      ka->a.status[b] = st;
     }
   }
 }
