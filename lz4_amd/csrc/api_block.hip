@@ -60,7 +60,7 @@ extern "C" size_t lz4mi_compress_bound(size_t n) { return bound(n); }
 
 // ----------------------------------------------------------------- context
 
-enum { kCounterDecode = 0 /* three words */, kCounterEncode = 4, kCounterHc = 5, kNumCounters = 16 };
+enum { kCounterDecode = 0 /* three words */, kCounterEncode = 4, kCounterHc = 5, kCounterOrder = 8 /* two words */, kNumCounters = 16 };
 
 static std::string g_create_error;  // reason of the last failed lz4mi_ctx_create
 
@@ -112,7 +112,7 @@ extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   DevBuf *bufs[] = {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
                     &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
                     &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
-                    &c->hc_chain, &c->hc_cnt, &c->hc_floor, &c->redo};
+                    &c->hc_chain, &c->hc_cnt, &c->hc_floor, &c->redo, &c->order};
   for (DevBuf *b : bufs) b->release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -203,7 +203,11 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
   uint32_t *counter = c->d_counters + kCounterDecode;
   LZ4MI_HIP(c, c->redo.ensure((size_t)a.nblocks * 16));
   LZ4MI_HIP(c, hipMemsetAsync(counter, 0, 3 * sizeof(uint32_t), c->stream));
-  launch_decode(a, strict, counter, counter + 2, c->redo.p, wave_grid(c, a.nblocks, 32), c->stream);
+  uint32_t *order_cnt = c->d_counters + kCounterOrder;
+  LZ4MI_HIP(c, hipMemsetAsync(order_cnt, 0, 2 * sizeof(uint32_t), c->stream));
+  LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
+  launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, getenv("LZ4MI_NO_ORDER") ? nullptr : c->order.as<uint32_t>(),
+                wave_grid(c, a.nblocks, 32), c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
 }

@@ -62,6 +62,8 @@ struct lz4mi_ctx {
   lz4mi::DevBuf hc_chain, hc_cnt, hc_floor;
   // decoder: blocks handed from the plain kernel to the group kernel (16 bytes per block)
   lz4mi::DevBuf redo;
+  // decoder: queue position -> block index of a launch (long blocks first)
+  lz4mi::DevBuf order;
 
   // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
   uint32_t shard_blocks = 0;

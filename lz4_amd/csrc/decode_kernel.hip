@@ -27,6 +27,7 @@ namespace lz4mi {
 
 #ifdef LZ4MI_PROFILE
 __device__ unsigned long long g_dec_phase[PH_SLOTS];
+__device__ unsigned long long g_dec_span[2 * 65536];  // per block: start and end (100 MHz ticks)
 #endif
 
 // 1 KiB of the compressed block in registers: lane l holds the dwords at v-space offsets
@@ -136,18 +137,42 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   }
   // Overlapping match: byte-serial forward copy semantics (byte_writer.dart:116-118)
   // == replication of the period [op-dist, op), which is complete before the match starts.
-  uint32_t r = dist >= kWave ? lane : lane % dist;
-  uint32_t step = dist > kWave ? kWave : kWave % dist;
-  for (uint32_t k = lane; k < ml; k += kWave) {
-    int64_t sp = s + r;
-    uint8_t v;
-    if (HAS_PREFIX && sp < 0)
-      v = prefix[(int64_t)prefix_len + sp];
-    else
-      v = dst[sp];
-    dst[op + k] = v;
-    r += step;
-    if (r >= dist) r -= dist;
+  // The first stretch is put down from the period itself (a plain copy of one period when the period
+  // is at least a wavefront wide, else 256 bytes through a modulo gather); after that the match's own
+  // output holds whole periods, and the rest is copied from it in spans that double each time
+  // (a span is a multiple of the period and never longer than what has been written, so source and
+  // destination of one copy do not overlap and it moves 16 bytes per lane).
+  uint32_t done;
+  if (dist >= kWave) {
+    if (!HAS_PREFIX || s >= 0) {
+      wave_copy(dst + op, dst + s, dist, lane);
+    } else {
+      uint32_t npre = (uint32_t)(-s) < dist ? (uint32_t)(-s) : dist;
+      wave_copy(dst + op, prefix + prefix_len + s, npre, lane);
+      if (dist > npre) wave_copy(dst + op + npre, dst, dist - npre, lane);
+    }
+    done = dist;
+  } else {
+    const uint32_t first = ml < 4 * kWave ? ml : 4 * kWave;
+    uint32_t r = lane % dist;
+    const uint32_t step = kWave % dist;
+    for (uint32_t k = lane; k < first; k += kWave) {
+      int64_t sp = s + r;
+      uint8_t v;
+      if (HAS_PREFIX && sp < 0)
+        v = prefix[(int64_t)prefix_len + sp];
+      else
+        v = dst[sp];
+      dst[op + k] = v;
+      r += step;
+      if (r >= dist) r -= dist;
+    }
+    done = first;
+  }
+  for (uint32_t span = done / dist * dist; done < ml; span *= 2) {
+    const uint32_t nb = ml - done < span ? ml - done : span;
+    wave_copy(dst + op + done, dst + op + done - span, nb, lane);
+    done += nb;
   }
   vm_quiesce();
 }
@@ -247,6 +272,10 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
       if ((++nseq & (HANDOVER - 1u)) == 0u) {
         if (op - mark < HANDOVER * kMsBytes) { st = kSwitchRun; break; }
         mark = op;
+        // a long block decides when the launch ends: it takes issue priority over its neighbours
+        if (nseq == 256) __builtin_amdgcn_s_setprio(1);
+        if (nseq == 512) __builtin_amdgcn_s_setprio(2);
+        if (nseq == 768) __builtin_amdgcn_s_setprio(3);
       }
     }
     uint32_t token = sbyte(w, sm, ip, lane);
@@ -501,6 +530,7 @@ struct DecodeKArgs {
   uint32_t *counter;
   uint32_t *redo_count;
   RedoEntry *redo;
+  const uint32_t *order;
 };
 typedef const volatile __attribute__((address_space(4))) DecodeKArgs *DecodeKArgsPtr;
 
@@ -530,7 +560,7 @@ __device__ __forceinline__ BlockIo block_io(DecodeKArgsPtr ka, uint32_t b) {
 
 template <bool STRICT, bool HAS_PREFIX>
 __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter, uint32_t *redo_count,
-                                                     RedoEntry *redo) {
+                                                     RedoEntry *redo, const uint32_t *order) {
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
   const uint32_t lane = lane_id();
   lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
@@ -545,13 +575,21 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
   uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
   for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
     if (b >= a.nblocks) break;
+    if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
     const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
     const uint32_t src_len = uni(block_src_len(a, b));
     uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t used = 0, out_len = 0;
+    __builtin_amdgcn_s_setprio(0);
+#ifdef LZ4MI_PROFILE
+    if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int32_t st = decode_run<STRICT, HAS_PREFIX, false, kMsEnter>(src, src_len, dst, 0, cap, prefix_len, prefix,
                                                                    prefix_len, ring, lane, used, out_len);
+#ifdef LZ4MI_PROFILE
+    if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (lane == 0) {
       if (st == kSwitchRun) {
         const uint32_t k = atomicAdd(redo_count, 1u);
@@ -566,7 +604,7 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
 }
 
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(256) void decode_redo_kernel(BatchArgs, uint32_t *, uint32_t *, RedoEntry *) {
+__global__ __launch_bounds__(256) void decode_redo_kernel(BatchArgs, uint32_t *, uint32_t *, RedoEntry *, const uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
   const uint32_t lane = lane_id();
   lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
@@ -631,6 +669,9 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
 }
 
 #ifdef LZ4MI_PROFILE
+extern "C" void lz4mi_debug_dec_spans(unsigned long long *out, int n) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_span), sizeof(unsigned long long) * 2 * n);
+}
 extern "C" void lz4mi_debug_dec_phases(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_phase), sizeof(unsigned long long) * PH_SLOTS);
   if (reset) {
@@ -645,26 +686,56 @@ void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
   hipLaunchKernelGGL(decode_chain_kernel, dim3(1), dim3(64), 0, s, c);
 }
 
+// A launch ends when its longest block does, and the queue hands blocks out in order: a long block
+// far down the queue starts late.  What a block costs the decoder shows in its size: literal-only
+// blocks (compressed >= about the output size) and run-like blocks (a few bytes) are streamed, the
+// ones in between are sequence after sequence on one wavefront.  Those go to the front of the queue.
+__global__ __launch_bounds__(256) void decode_order_kernel(BatchArgs a, uint32_t *cnt, uint32_t *order) {
+  const uint32_t lane = lane_id();
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = b < a.nblocks;
+  bool heavy = false;
+  if (valid) {
+    const uint64_t c = block_src_len(a, b), n = a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform;
+    heavy = c * 16 < n * 15 && c * 32 > n;
+  }
+  const uint64_t hm = ballot(heavy), lm = ballot(valid && !heavy);
+  uint32_t bh = 0, bl = 0;
+  if (lane == 0) {
+    if (hm) bh = atomicAdd(cnt, (uint32_t)__builtin_popcountll(hm));
+    if (lm) bl = atomicAdd(cnt + 1, (uint32_t)__builtin_popcountll(lm));
+  }
+  bh = uni(bh);
+  bl = uni(bl);
+  const uint64_t below = (1ull << lane) - 1ull;
+  if (heavy) order[bh + (uint32_t)__builtin_popcountll(hm & below)] = b;
+  else if (valid) order[a.nblocks - 1u - (bl + (uint32_t)__builtin_popcountll(lm & below))] = b;
+}
+
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *redo_count, void *redo,
-                   uint32_t grid, hipStream_t s) {
+                   uint32_t *order_cnt, uint32_t *order, uint32_t grid, hipStream_t s) {
+  if (order && a.nblocks > grid * 4u)  // only a queued launch has an order to choose
+    hipLaunchKernelGGL(decode_order_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, s, a, order_cnt, order);
+  else
+    order = nullptr;
   dim3 g(grid), blk(256);
   RedoEntry *r = (RedoEntry *)redo;
   const bool pre = a.dict_len != 0;
   if (strict) {
     if (pre) {
-      hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r);
-      hipLaunchKernelGGL((decode_redo_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r, order);
+      hipLaunchKernelGGL((decode_redo_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r, order);
     } else {
-      hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r);
-      hipLaunchKernelGGL((decode_redo_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r, order);
+      hipLaunchKernelGGL((decode_redo_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r, order);
     }
   } else {
     if (pre) {
-      hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r);
-      hipLaunchKernelGGL((decode_redo_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r, order);
+      hipLaunchKernelGGL((decode_redo_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r, order);
     } else {
-      hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r);
-      hipLaunchKernelGGL((decode_redo_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r);
+      hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r, order);
+      hipLaunchKernelGGL((decode_redo_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r, order);
     }
   }
 }

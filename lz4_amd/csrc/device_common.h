@@ -84,6 +84,15 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
   if (lane < head) hb = src[lane];
   if (lane < tail) tb = s[body + lane];
   uint32_t off = lane * 16;
+  // long copies keep 8 KiB in flight per round trip (one wavefront alone is bound by the latency
+  // of a round trip, not by bandwidth)
+  for (; off + 7 * 1024 < body; off += 8192) {
+    U128U v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ld128(s + off + 1024 * k);
+#pragma unroll
+    for (int k = 0; k < 8; k++) st128(d + off + 1024 * k, v[k]);
+  }
   for (; off + 3 * 1024 < body; off += 4096) {
     U128U a = ld128(s + off), b = ld128(s + off + 1024), c = ld128(s + off + 2048), e = ld128(s + off + 3072);
     st128(d + off, a);
