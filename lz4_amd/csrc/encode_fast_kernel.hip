@@ -381,6 +381,24 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         fwd = 8 * L + rdlane(eq, 32 + L);
       } else {  // longer than 256 bytes: 1 KiB per step
         fwd = 256;
+        // a very long match (a run, a short period) is one dependent chain of round trips: 4 KiB per
+        // trip while that much lies in front of the match limit and the reference side is block data
+        while (i + 4 + fwd + 4096 <= elimit && i + 4 + fwd - dist >= D) {
+          const uint8_t *pa = in.src + (i + 4 + fwd - D) + 16 * lane, *pb = pa - dist;
+          U128U a[4], c[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) { a[k] = ld128(pa + 1024 * k); c[k] = ld128(pb + 1024 * k); }
+          uint32_t e16[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint64_t x0 = (((uint64_t)(a[k].b ^ c[k].b)) << 32) | (a[k].a ^ c[k].a);
+            const uint64_t x1 = (((uint64_t)(a[k].d ^ c[k].d)) << 32) | (a[k].c ^ c[k].c);
+            e16[k] = x0 ? (uint32_t)__builtin_ctzll(x0) >> 3 : (x1 ? 8u + ((uint32_t)__builtin_ctzll(x1) >> 3) : 16u);
+          }
+          const uint64_t m0 = ballot(e16[0] < 16), m1 = ballot(e16[1] < 16), m2 = ballot(e16[2] < 16), m3 = ballot(e16[3] < 16);
+          if (m0 | m1 | m2 | m3) break;  // the end is inside these 4 KiB: the 1 KiB loop below finds it
+          fwd += 4096;
+        }
         for (;;) {
           const uint32_t pp = i + 4 + fwd + 16 * lane;
           const uint32_t e16 = eq16g<HAS_DICT>(in, w, pp, pp - dist, elimit);

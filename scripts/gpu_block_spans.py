@@ -32,3 +32,5 @@ for name, fn in (('enc', L.lz4mi_debug_enc_spans), ('dec', L.lz4mi_debug_dec_spa
     # how many blocks are running over time
     for t in (100, 300, 500, 800, 1000, 1500, 2000, 2500):
         print(f"    t={t}: running {(int(((s<=t)&(e>t)).sum()))} heavy running {int(((s<=t)&(e>t)&heavy).sum())} not started {int((s>t).sum())}")
+    cls = np.arange(NB) % 8
+    print("  per class mean/max duration us:", {int(c): (round(float(d[cls == c].mean())), round(float(d[cls == c].max()))) for c in range(8)})
