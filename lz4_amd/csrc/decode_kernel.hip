@@ -273,9 +273,9 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         if (op - mark < HANDOVER * kMsBytes) { st = kSwitchRun; break; }
         mark = op;
         // a long block decides when the launch ends: it takes issue priority over its neighbours
-        if (nseq == 256) __builtin_amdgcn_s_setprio(1);
-        if (nseq == 512) __builtin_amdgcn_s_setprio(2);
-        if (nseq == 768) __builtin_amdgcn_s_setprio(3);
+        if (nseq == 64) __builtin_amdgcn_s_setprio(1);
+        if (nseq == 192) __builtin_amdgcn_s_setprio(2);
+        if (nseq == 448) __builtin_amdgcn_s_setprio(3);
       }
     }
     uint32_t token = sbyte(w, sm, ip, lane);

@@ -240,6 +240,119 @@ def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle):
             assert n_ok >= 12
 
 
+def _lz4_len(v):
+    out = bytearray()
+    while v >= 255:
+        out.append(255)
+        v -= 255
+    out.append(v)
+    return bytes(out)
+
+
+def _sequence(lits, dist, ml):
+    """One LZ4 sequence: literals, then a match of ml >= 4 bytes at distance dist."""
+    m4 = ml - 4
+    out = bytearray([(min(len(lits), 15) << 4) | min(m4, 15)])
+    if len(lits) >= 15:
+        out += _lz4_len(len(lits) - 15)
+    out += lits + bytes([dist & 255, dist >> 8])
+    if m4 >= 15:
+        out += _lz4_len(m4 - 15)
+    return bytes(out)
+
+
+def _last_literals(lits):
+    out = bytearray([min(len(lits), 15) << 4])
+    if len(lits) >= 15:
+        out += _lz4_len(len(lits) - 15)
+    return bytes(out + lits)
+
+
+def test_block_decoder_long_overlapping_matches(codec, oracle):
+    """Matches longer than their distance (byte-serial copyMatch, lib/src/internal/byte_writer.dart:116-118)
+    and longer than the decoder's short-copy path: every distance class (below / at / above a
+    wavefront, around 16-byte alignment), lengths up to more than a block, sources that start inside
+    a dictionary prefix, followed by a second match that reads the replicated bytes back."""
+    import torch
+    rng = np.random.default_rng(5)
+    dictionary = bytes(rng.integers(0, 256, size=5000, dtype=np.uint8))
+    dists = [1, 2, 3, 5, 7, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 255, 256, 257, 1000, 4097]
+    lens = [257, 258, 300, 511, 1023, 4101, 8192, 20000, 70000]
+    for use_dict in (False, True):
+        cases = []
+        for d in dists:
+            for ml in lens:
+                if ml <= d:
+                    continue
+                nlit = int(rng.integers(0, 40)) if use_dict else d + int(rng.integers(0, 40))
+                lits = bytes(rng.integers(0, 256, size=nlit, dtype=np.uint8))
+                d2 = int(rng.integers(1, min(nlit + ml, 65535) + 1))
+                blk = _sequence(lits, d, ml) + _sequence(b"xy", d2, 19) + _last_literals(b"tail!")
+                cases.append((blk, nlit + ml + 2 + 19 + 5))
+        offs, blob = [], bytearray()
+        for s_, _ in cases:
+            offs.append(len(blob))
+            blob += s_
+        blob += bytes(64)
+        comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+        sizes = torch.tensor([len(s_) for s_, _ in cases], dtype=torch.int32, device="cuda")
+        offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        expected = torch.tensor([z for _, z in cases], dtype=torch.int32, device="cuda")
+        dict_t = torch.tensor(np.frombuffer(dictionary, dtype=np.uint8).copy(), device="cuda") if use_dict else None
+        slot = 75008
+        for strict in ((False,) if use_dict else (True, False)):
+            out, out_len, status = codec.decompress_blocks(comp, sizes, slot, comp_offsets=offsets, expected=expected,
+                                                           strict=strict, dictionary=dict_t)
+            out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+            for k, (s_, z) in enumerate(cases):
+                pre = dictionary if use_dict else b""
+                ref = oracle.block_decompress(s_, z) if strict else oracle.block_decompress_into(s_, pre, len(pre) + z)[len(pre):]
+                assert int(status[k]) == 0, (use_dict, strict, k)
+                assert int(out_len[k]) == len(ref) == z
+                assert out[k, :z].tobytes() == ref, (use_dict, strict, k)
+
+
+def test_block_decoder_queue_order_large_ragged_batch(codec, oracle):
+    """More blocks than resident wavefronts, so the launch goes through the work queue and its
+    long-blocks-first order: blocks of very different sizes and kinds (literal-only, run-like, mixed,
+    damaged) all come back with the oracle's bytes and status at their own index."""
+    import torch
+    rng = np.random.default_rng(77)
+    kinds = []
+    for i in range(24):
+        n = int(rng.integers(1, 1500))
+        data = corpus_block(i, 2048).tobytes()[:n]
+        kinds.append((oracle.block_compress_fast(data), n))
+        kinds.append((oracle.block_compress_hc(data, max_search_depth=4), n))
+    kinds.append((_sequence(b"ab", 2, 1200) + _last_literals(b"z"), 1203))
+    kinds.append((bytes([0x1F, 0x41, 9, 0, 200]), 300))  # distance beyond the output: corrupt
+    nb = 24000
+    pick = rng.integers(0, len(kinds), size=nb)
+    offs, blob = [], bytearray()
+    for k in pick:
+        offs.append(len(blob))
+        blob += kinds[int(k)][0]
+    blob += bytes(64)
+    comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+    sizes = torch.tensor([len(kinds[int(k)][0]) for k in pick], dtype=torch.int32, device="cuda")
+    offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    expected = torch.tensor([kinds[int(k)][1] for k in pick], dtype=torch.int32, device="cuda")
+    out, out_len, status = codec.decompress_blocks(comp, sizes, 1536, comp_offsets=offsets, expected=expected, strict=True)
+    out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+    refs = []
+    for s_, z in kinds:
+        try:
+            refs.append((oracle.block_decompress(s_, z), 0))
+        except oracle.Lz4RefError as e:
+            refs.append((None, e.status))
+    for i, k in enumerate(pick):
+        ref, st = refs[int(k)]
+        assert int(status[i]) == st, (i, int(k))
+        if ref is not None:
+            assert int(out_len[i]) == len(ref)
+            assert out[i, : len(ref)].tobytes() == ref, (i, int(k))
+
+
 # --------------------------------------------------------------- encoder
 
 def test_encoder_byte_known_answers(lz):
