@@ -163,19 +163,19 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
 // One re-hash step: table[hash] = position for up to 64 ascending positions.  Inserts go out as
 // plain stores (a store to a line that is not cached needs no fetch, an atomic does).  Positions
 // rise with the lane, so of the lanes of one instruction that share a bucket only the highest may
-// store: each lane max-claims a slot of a small LDS array with its lane number and looks at the
-// winner's hash.  Same hash: the winner is the bucket's highest lane.  Different hash (two buckets
-// met in one slot): undecided, those lanes fall back to the atomic max, which is always right.
+// store: each lane max-claims a slot of a small LDS array with (lane + 1, hash) and reads the winner
+// back.  Same hash: the winner is the bucket's highest lane.  Different hash (two buckets met in one
+// slot): undecided, those lanes fall back to the atomic max, which is always right.
 __device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_t hj, uint32_t value, bool live,
                                             uint32_t lane) {
   lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
-  if (live) (void)__hip_atomic_fetch_max(slot, lane + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  const uint32_t top = live ? *slot : lane + 1;
-  const uint32_t htop = (uint32_t)__shfl((int)hj, (int)(top - 1));
+  const uint32_t mine = ((lane + 1) << 16) | hj;
+  if (live) (void)__hip_atomic_fetch_max(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  const uint32_t top = live ? *slot : mine;
   if (live) {
     *slot = 0;
-    if (htop != hj) tbl_max(T + hj, value);
-    else if (top == lane + 1) tbl_store(T + hj, value);
+    if ((top & 0xFFFFu) != hj) tbl_max(T + hj, value);
+    else if (top == mine) tbl_store(T + hj, value);
   }
 }
 
@@ -233,6 +233,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       uint32_t ik = anchor + offA;
       bool valid = lane < kFirst && ik + 4 <= plimit;
       uint32_t seq = w32(w, ik - D);
+      // the first 64 bytes the sequence will be written from (its literals start at s, behind a one- or
+      // two-byte header): read now, in the same LDS round trip as the probe bytes
+      const uint32_t lit1 = w8(w, s + lane - 1), lit2 = w8(w, s + lane - 2);
       uint32_t h = hash16(seq);
       int32_t ref = -1;
       {
@@ -428,7 +431,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u);
           for (uint32_t base = 0; base < slen; base += kWave) {
             const uint32_t x = base + lane;
-            uint32_t v = w8(w, s + x - h0);
+            uint32_t v = base == 0 ? (e1 ? lit2 : lit1) : w8(w, s + x - h0);
             if (x >= px) v = x + 1 == slen ? (m4 - 15) % 255u : 255u;
             if (x == po) v = dist & 0xFFu;
             if (x == po + 1) v = dist >> 8;
