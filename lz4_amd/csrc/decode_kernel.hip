@@ -177,21 +177,6 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   vm_quiesce();
 }
 
-// Inclusive prefix sum over the 64 lanes: row shifts inside the 16-lane rows, then the two row
-// broadcasts (lanes without a source add zero).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
-  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
-  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
-  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
-  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
 __device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t from) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v);
 }

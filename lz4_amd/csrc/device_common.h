@@ -26,7 +26,7 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
   return __builtin_amdgcn_readlane(v, l);
 }
-__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // Explicit "all vector-memory operations done" (vmcnt(0) alone).  Placed where the wavefront has
 // just consumed its last outstanding load, it costs nothing and tells the compiler's wait
@@ -112,6 +112,21 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
   if (h2) st128(d + off + 2048, r2);
 }
 
+// Inclusive prefix sum over the 64 lanes: row shifts inside the 16-lane rows, then the two row
+// broadcasts (lanes without a source add zero).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
 // xxHash32 constants (lib/src/xxhash/xxh32.dart:3-7).
 constexpr uint32_t XP1 = 0x9E3779B1u, XP2 = 0x85EBCA77u, XP3 = 0xC2B2AE3Du, XP4 = 0x27D4EB2Fu,
                    XP5 = 0x165667B1u;

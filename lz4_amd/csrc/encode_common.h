@@ -72,7 +72,7 @@ __device__ __forceinline__ uint64_t same_hash_lanes(uint32_t h, uint64_t vmask) 
   uint64_t same = vmask;
   for (uint32_t bit = 0; bit < 16; bit++) {
     bool set = (h >> bit) & 1u;
-    uint64_t m = __ballot(set);
+    uint64_t m = ballot(set);
     same &= set ? m : ~m;
   }
   return same;
@@ -84,7 +84,7 @@ __device__ __forceinline__ uint64_t same_hash_lanes(uint32_t h, uint64_t vmask) 
 // have been reduced to the last one (largest position).  Plain stores stay in the XCD's L2;
 // device-scope atomics would execute at the memory side and evict the line.
 __device__ __forceinline__ void tbl_insert(uint32_t *T, uint32_t h, uint32_t v, bool valid, uint32_t lane) {
-  const uint64_t vmask = __ballot(valid);
+  const uint64_t vmask = ballot(valid);
   const uint64_t same = same_hash_lanes(h, vmask);
   const uint64_t later = same & ~((2ull << lane) - 1ull);
   if (valid && !later) T[h] = v;

@@ -191,11 +191,64 @@ __device__ __forceinline__ uint32_t shr_min(uint32_t h) {
   }
 }
 
+// Writing a sequence (_writeSequence, :172-200) is not on the path to the next match, so it is taken
+// off the serial chain: a found sequence is noted in LDS (literal start, literal length, distance,
+// match length) and up to kBatch of them are written together.  Lane j sizes sequence j, a prefix
+// sum places it, the lane writes its token, length bytes and offset; the literal runs follow one
+// after the other, wave-wide, out of the input ring when it still holds them.
+constexpr uint32_t kBatch = 32;
+__device__ __forceinline__ uint32_t write_sequences(const Win &w, lds_u32 *desc, uint32_t cnt, uint8_t *out, uint32_t op,
+                                                    uint32_t lane) {
+  const bool mine = lane < cnt;
+  uint32_t s = 0, lit = 0, dist = 0, ml = 4;
+  if (mine) {
+    const u32x4 d = *(lds_u128 *)(desc + 4 * lane);
+    s = d.x; lit = d.y; dist = d.z; ml = d.w;
+  }
+  const uint32_t m4 = ml - 4;
+  const uint32_t e1 = lit >= 15 ? (lit - 15) / 255u + 1u : 0u;  // _writeLength :216-223: v / 255 bytes of 255, then v % 255
+  const uint32_t mx = m4 >= 15 ? (m4 - 15) / 255u + 1u : 0u;
+  const uint32_t size = mine ? 1 + e1 + lit + 2 + mx : 0u;
+  const uint32_t incl = wave_incl_scan(size);
+  const uint32_t base = op + incl - size;
+  const uint32_t lpos = base + 1 + e1;  // where the literals go
+  if (mine) {
+    out[base] = (uint8_t)(((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u));
+    for (uint32_t k = 0; k < e1; k++) out[base + 1 + k] = k + 1 < e1 ? (uint8_t)255 : (uint8_t)((lit - 15) % 255u);
+    const uint32_t q = lpos + lit;
+    out[q] = (uint8_t)dist;
+    out[q + 1] = (uint8_t)(dist >> 8);
+    for (uint32_t k = 0; k < mx; k++) out[q + 2 + k] = k + 1 < mx ? (uint8_t)255 : (uint8_t)((m4 - 15) % 255u);
+  }
+  // runs of up to 64 bytes that the ring still holds (nearly all): four per LDS round trip
+  const uint64_t slow = ballot(mine && lit != 0 && !(lit <= kWave && s >= w.lo));  // s + lit <= anchor <= w.hi
+  for (uint32_t j = 0; j < cnt; j += 4) {
+    uint32_t lj[4], dj[4], v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t jj = j + u;  // lanes at or past cnt hold lit = 0
+      lj[u] = ((slow >> jj) & 1ull) ? 0u : rdlane(lit, jj);
+      dj[u] = rdlane(lpos, jj);
+      v[u] = w8(w, rdlane(s, jj) + lane);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++)
+      if (lane < lj[u]) out[dj[u] + lane] = (uint8_t)v[u];
+  }
+  for (uint64_t m = slow; m; m &= m - 1) {  // long runs, runs the ring has dropped
+    const uint32_t j = (uint32_t)__builtin_ctzll(m);
+    wave_copy(out + rdlane(lpos, j), w.src + rdlane(s, j), rdlane(lit, j), lane);
+  }
+  if (slow) vm_quiesce();  // rare path: leave no load pending
+  return op + rdlane(incl, kWave - 1);
+}
+
 template <bool HAS_DICT, bool LINKED>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
-                                                     lds_u32 *claim, uint32_t lane, uint32_t &out_len) {
+                                                     lds_u32 *claim, lds_u32 *desc, uint32_t lane,
+                                                     uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t plimit = in.plimit, elimit = in.elimit;
@@ -217,6 +270,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       }
     }
     Win w = {lds, in.src, n, 0, 0};
+    uint32_t nbatch = 0;  // sequences found and not yet written
     while (anchor + 4 <= plimit) {  // one iteration per sequence
       const uint32_t s = anchor - D;
       {
@@ -233,9 +287,6 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       uint32_t ik = anchor + offA;
       bool valid = lane < kFirst && ik + 4 <= plimit;
       uint32_t seq = w32(w, ik - D);
-      // the first 64 bytes the sequence will be written from (its literals start at s, behind a one- or
-      // two-byte header): read now, in the same LDS round trip as the probe bytes
-      const uint32_t lit1 = w8(w, s + lane - 1), lit2 = w8(w, s + lane - 2);
       uint32_t h = hash16(seq);
       int32_t ref = -1;
       {
@@ -417,33 +468,13 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       vm_quiesce();  // every read of this sequence is done; only writes follow
       const uint32_t ml = b + 4 + fwd;
       const uint32_t lit = ms - anchor;
-      const uint32_t m4 = ml - 4;
       PH(5);
 
-      // ---- _writeSequence :172-200
-      {
-        const uint32_t e1 = lit >= 15 ? 1u : 0u;                       // one extension byte covers lit <= 269
-        const uint32_t mx = m4 >= 15 ? (m4 - 15) / 255u + 1u : 0u;     // match-length extension bytes
-        const uint32_t slen = 1 + e1 + lit + 2 + mx;
-        if (lit <= 200 && slen <= 2 * kWave) {
-          // the whole sequence is one or two wave-wide byte stores; literals come from the ring
-          const uint32_t h0 = 1 + e1, po = h0 + lit, px = po + 2;
-          const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (m4 < 15 ? m4 : 15u);
-          for (uint32_t base = 0; base < slen; base += kWave) {
-            const uint32_t x = base + lane;
-            uint32_t v = base == 0 ? (e1 ? lit2 : lit1) : w8(w, s + x - h0);
-            if (x >= px) v = x + 1 == slen ? (m4 - 15) % 255u : 255u;
-            if (x == po) v = dist & 0xFFu;
-            if (x == po + 1) v = dist >> 8;
-            if (x == 1 && e1) v = lit - 15;
-            if (x == 0) v = token;
-            if (x < slen) out[op + x] = (uint8_t)v;
-          }
-          op += slen;
-        } else {
-          op = emit_sequence(out, op, in.src + s, lit, dist, ml, lane);
-          vm_quiesce();  // rare path: leave no load pending at the join
-        }
+      // ---- _writeSequence :172-200, deferred: the sequence is noted down and written with its batch
+      if (lane < 4) desc[4 * nbatch + lane] = lane == 0 ? s : lane == 1 ? lit : lane == 2 ? dist : ml;
+      if (++nbatch == kBatch) {
+        op = write_sequences(w, desc, nbatch, out, op, lane);
+        nbatch = 0;
       }
       anchor = ms + ml;  // :132-133
       if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe of the last chunk up to the hit
@@ -469,6 +500,7 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       }
       PH(7);
     }
+    if (nbatch) op = write_sequences(w, desc, nbatch, out, op, lane);
   }
   // _writeLastLiterals :153-156, :202-214
   const uint32_t last = total - anchor;
@@ -495,6 +527,7 @@ template <bool HAS_DICT, bool LINKED>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[4][kClaimSlots];
+  __shared__ __attribute__((aligned(16))) uint32_t s_desc[4][4 * kBatch];
   EncodeKArgsPtr ka = (EncodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
@@ -557,7 +590,8 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
     if (lane == 0 && b < 65536) g_enc_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     int32_t st = encode_block_fast<HAS_DICT, LINKED>(in, out, cap, sh, T, dictT, gen, offA, offB,
-                                                     (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane, out_len);
+                                                     (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], (lds_u32 *)s_desc[wave], lane,
+                                                     out_len);
 #ifdef LZ4MI_PROFILE
     if (lane == 0 && b < 65536) g_enc_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
