@@ -165,16 +165,29 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
 // rise with the lane, so of the lanes of one instruction that share a bucket only the highest may
 // store: each lane max-claims a slot of a small LDS array with (lane + 1, hash) and reads the winner
 // back.  Same hash: the winner is the bucket's highest lane.  Different hash (two buckets met in one
-// slot): undecided, those lanes fall back to the atomic max, which is always right.
+// slot): undecided; after a second round the few lanes still undecided fall back to the atomic max,
+// which is always right.
 __device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_t hj, uint32_t value, bool live,
                                             uint32_t lane) {
-  lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
   const uint32_t mine = ((lane + 1) << 16) | hj;
+  lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
   if (live) (void)__hip_atomic_fetch_max(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  const uint32_t top = live ? *slot : mine;
+  uint32_t top = live ? *slot : mine;
+  if (live) *slot = 0;
+  bool open = live && (top & 0xFFFFu) != hj;
+  if (ballot(open)) {
+    // Lanes that met another bucket in their slot vote again among themselves, on the other half of
+    // the hash (lanes of one bucket share their fate in every round, so the vote stays complete).
+    // An atomic in front of the next table gather costs that gather the atomic's whole round trip,
+    // which under load is several times the gather's own; a second LDS round trip is cheap next to it.
+    lds_u32 *slot2 = claim + ((hj >> 8) & (kClaimSlots - 1));
+    if (open) (void)__hip_atomic_fetch_max(slot2, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (open) top = *slot2;
+    if (open) *slot2 = 0;
+    open = open && (top & 0xFFFFu) != hj;
+  }
   if (live) {
-    *slot = 0;
-    if ((top & 0xFFFFu) != hj) tbl_max(T + hj, value);
+    if (open) tbl_max(T + hj, value);
     else if (top == mine) tbl_store(T + hj, value);
   }
 }
@@ -303,12 +316,14 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       { uint64_t w_ = ballot(ref >= 0); asm volatile("" ::"s"(w_)); }
 #endif
       PH(1);
+      bool dup;  // probes of the current step share a bucket: their inserts have to be atomic maxima
       {
         // Earlier probes of the run that land in the same bucket act as the table entry (:99-100
         // in program order).  Equal hashes among the first probes are rare: detect with row shifts, resolve
         // out of line.
         const uint32_t mn = shr_min<kFirst - 1>(h);
-        if (ballot(valid && mn == 0)) {
+        dup = ballot(valid && mn == 0) != 0;
+        if (dup) {
           for (uint32_t j = 0; j + 1 < nvalid; j++) {  // nearest earlier lane with an equal hash wins
             const uint32_t hj = rdlane(h, j), ij = rdlane(ik, j);
             if (valid && lane > j && h == hj) ref = (int32_t)ij;
@@ -333,7 +348,10 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
 
       // ---- the rest of the run, 64 probes at a time
       if (!hm && nvalid == kFirst) {
-        if (valid) tbl_max(T + h, gtag | (ik + 1));  // :100, all of them missed
+        if (valid) {  // :100, all of them missed
+          if (dup) tbl_max(T + h, gtag | (ik + 1));
+          else tbl_store(T + h, gtag | (ik + 1));
+        }
         valid = false;
         uint32_t o_last = 0;
         for (uint32_t chunk = 1;; chunk++) {
@@ -367,13 +385,17 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
             const uint32_t j = peers ? 63u - (uint32_t)__builtin_clzll(peers) : lane;
             const uint32_t ij = (uint32_t)__shfl((int)ik, (int)j);
             if (peers) ref = (int32_t)ij;
+            dup = ballot(peers != 0) != 0;
           }
           bool hit = false;
           if (valid && ref >= 0 && ik - (uint32_t)ref <= 0xFFFFu) hit = rd32<HAS_DICT>(in, w, (uint32_t)ref) == seq;
           hm = ballot(hit);
           K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
-          if (hm) break;  // the probes up to the hit are inserted once the sequence is written
-          if (valid) tbl_max(T + h, gtag | (ik + 1));
+          if (hm) break;  // the probes up to the hit are inserted once the match is known
+          if (valid) {
+            if (dup) tbl_max(T + h, gtag | (ik + 1));
+            else tbl_store(T + h, gtag | (ik + 1));
+          }
           valid = false;
           if (nvalid < kWave) break;
           o_last = rdlane(o, kWave - 1);
@@ -477,7 +499,13 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         nbatch = 0;
       }
       anchor = ms + ml;  // :132-133
-      if (valid && lane <= K) tbl_max(T + h, gtag | (ik + 1));  // :100 for every probe of the last chunk up to the hit
+      if (valid && lane <= K) {  // :100 for every probe of the last step up to the hit
+        // Every insert is at a larger position than the bucket held, and a wavefront's stores to one
+        // address land in issue order, so a plain store does as long as no two lanes of THIS
+        // instruction share a bucket.
+        if (dup) tbl_max(T + h, gtag | (ik + 1));
+        else tbl_store(T + h, gtag | (ik + 1));
+      }
       PH(6);
 
       // ---- :135-145 interior re-hash, last `dist` positions only
