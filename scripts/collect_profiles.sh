@@ -14,4 +14,5 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w -f csv -- 
 cp $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $out/pmc_fetch.csv
 cp $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_write.csv
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+python scripts/traffic_from_pmc.py $out $out/traffic.json
 ls -la $out
