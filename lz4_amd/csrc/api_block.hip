@@ -239,7 +239,7 @@ static void to_args(const lz4mi_batch *b, BatchArgs &a) {
 
 extern "C" int32_t lz4mi_compress_fast_batch(lz4mi_ctx *c, const lz4mi_batch *b, int64_t acceleration) {
   if (!c || !b) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   BatchArgs a;
   to_args(b, a);
   return run_compress_fast(c, a, acceleration);
@@ -247,7 +247,7 @@ extern "C" int32_t lz4mi_compress_fast_batch(lz4mi_ctx *c, const lz4mi_batch *b,
 
 extern "C" int32_t lz4mi_compress_hc_batch(lz4mi_ctx *c, const lz4mi_batch *b, int64_t depth) {
   if (!c || !b) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   BatchArgs a;
   to_args(b, a);
   return run_compress_hc(c, a, depth);
@@ -255,7 +255,7 @@ extern "C" int32_t lz4mi_compress_hc_batch(lz4mi_ctx *c, const lz4mi_batch *b, i
 
 extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, int32_t strict) {
   if (!c || !b) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   BatchArgs a;
   to_args(b, a);
   return run_decompress(c, a, strict != 0);
@@ -263,7 +263,7 @@ extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, in
 
 extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_t *d_hash) {
   if (!c || !b || !d_hash) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   BatchArgs a;
   to_args(b, a);
   launch_xxh32_batch(a, d_hash, c->stream);
@@ -274,7 +274,7 @@ extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_
 extern "C" int32_t lz4mi_xxh32_device(lz4mi_ctx *c, const uint8_t *d_data, uint64_t len, uint32_t seed,
                                       uint32_t *d_out) {
   if (!c || !d_out) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   launch_xxh32_serial(d_data, len, seed, d_out, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
@@ -292,7 +292,7 @@ struct OneResult {
 // Runs one block through a batch kernel: src (+dict) up, result down.
 int32_t one_block(lz4mi_ctx *c, const uint8_t *src, size_t n, const uint8_t *dict, size_t dict_len,
                   size_t dev_out_bytes, uint32_t cap_field, int kind, int64_t param, OneResult *res) {
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   LZ4MI_HIP(c, c->in.ensure(n + 16));
   LZ4MI_HIP(c, c->out.ensure(dev_out_bytes + 16));
   LZ4MI_HIP(c, c->comp_len.ensure(16));
@@ -392,7 +392,7 @@ extern "C" int32_t lz4mi_block_decompress_into(lz4mi_ctx *c, const uint8_t *src,
 
 extern "C" int32_t lz4mi_xxh32(lz4mi_ctx *c, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out) {
   if (!c || !out) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   LZ4MI_HIP(c, c->in.ensure(len + 16));
   LZ4MI_HIP(c, c->words.ensure(64));
   int32_t st = pin_reserve(c, 64);

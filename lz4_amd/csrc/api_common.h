@@ -80,6 +80,13 @@ inline int32_t fail(lz4mi_ctx *c, hipError_t e, const char *what) {
   return LZ4MI_BACKEND;
 }
 
+// First HIP call of every entry point: makes the context's device current and drops an error code
+// left behind by the caller's own HIP calls (hipGetLastError after a launch would report it as ours).
+inline hipError_t enter_device(lz4mi_ctx *c) {
+  (void)hipGetLastError();
+  return hipSetDevice(c->device);
+}
+
 #define LZ4MI_HIP(c, call)                                   \
   do {                                                       \
     hipError_t e_ = (call);                                  \

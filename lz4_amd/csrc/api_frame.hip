@@ -192,7 +192,7 @@ extern "C" int32_t lz4mi_frame_shard_compress(lz4mi_ctx *c, const uint8_t *d_src
   int32_t st = validate_options(o);
   if (st) return st;
   if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;  // a rank's first block would need the previous rank's bytes
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   st = shard_compress(c, d_src, n, o, d_dict, dict_len, nblocks_out);
   if (st) return st;
   if (d_record_sizes && *nblocks_out)
@@ -206,7 +206,7 @@ extern "C" int32_t lz4mi_frame_shard_write(lz4mi_ctx *c, const uint8_t *d_src, u
                                            uint8_t *d_dst, uint64_t cap) {
   (void)d_src; (void)n; (void)o; (void)cap;
   if (!c || !d_record_offsets || !d_dst) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   return shard_write(c, d_record_offsets, d_dst);
 }
 
@@ -216,7 +216,7 @@ extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src,
   if (!c) return LZ4MI_RANGE;
   int32_t st = validate_options(o);
   if (st) return st;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   if (cap < lz4mi_frame_bound((size_t)n, o)) return LZ4MI_DST_TOO_SMALL;
   uint8_t hdr[32];
   const size_t hlen = build_header(o, hdr);
@@ -244,7 +244,7 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   if (out_len) *out_len = 0;
   int32_t st = validate_options(o);
   if (st) return st;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   const size_t fb = lz4mi_frame_bound(n, o);
   LZ4MI_HIP(c, c->in.ensure(n + 16));
   LZ4MI_HIP(c, c->out.ensure(fb + 16));
@@ -520,7 +520,7 @@ extern "C" int32_t lz4mi_frame_decode_next(lz4mi_ctx *c, const uint8_t *src, siz
   if (!c || !consumed || !out_len) return LZ4MI_RANGE;
   *consumed = 0;
   *out_len = 0;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   if (len < 4) return LZ4MI_FORMAT_EOF;  // lz4_frame_decoder.dart:53-55
   const uint32_t magic = rd32(src);
   size_t off = 4;

@@ -50,7 +50,7 @@ int32_t xxh_state_update(lz4mi_ctx *c, lz4mi_xxh32_state *s, const uint8_t *data
   const size_t stripes = len / 16;
   if (stripes) {  // :83-118 on the device
     if (!c) return LZ4MI_RANGE;
-    LZ4MI_HIP(c, hipSetDevice(c->device));
+    LZ4MI_HIP(c, ::lz4mi::enter_device(c));
     const uint8_t *dp = nullptr;
     if (d_data) {
       dp = d_data + p;
@@ -172,7 +172,7 @@ extern "C" int32_t lz4mi_legacy_frame_encode(lz4mi_ctx *c, const uint8_t *src, s
   }
   if (acceleration < 1) return LZ4MI_RANGE;
   if (n / kLegacyBlockMax > 0x7ffffff0u) return LZ4MI_RANGE;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   const uint32_t nb = (uint32_t)((n + kLegacyBlockMax - 1) / kLegacyBlockMax);
   const size_t blk = n < kLegacyBlockMax ? n : kLegacyBlockMax;
   const size_t stride = round_up(bound(blk), 64);
@@ -293,7 +293,7 @@ extern "C" int32_t lz4mi_frame_encoder_create(lz4mi_ctx *c, const lz4mi_frame_op
   *out = nullptr;
   int32_t st = validate_options(o);
   if (st) return st;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   lz4mi_frame_encoder *e = new (std::nothrow) lz4mi_frame_encoder();
   if (!e) return LZ4MI_BACKEND;
   e->c = c;
@@ -340,7 +340,7 @@ extern "C" int32_t lz4mi_frame_encoder_update(lz4mi_frame_encoder *e, const uint
   if (e->finished) return LZ4MI_RANGE;
   if (n == 0) return LZ4MI_OK;  // :160-162
   lz4mi_ctx *c = e->c;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   e->total_in += n;
   if (e->o.has_content_size && e->total_in > e->o.content_size)  // :165-167
     return LZ4MI_FORMAT_CONTENT_SIZE_STREAM;
@@ -378,7 +378,7 @@ extern "C" int32_t lz4mi_frame_encoder_finish(lz4mi_frame_encoder *e, uint8_t *d
   *out_len = 0;
   if (e->finished) return LZ4MI_RANGE;
   lz4mi_ctx *c = e->c;
-  LZ4MI_HIP(c, hipSetDevice(c->device));
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
   size_t w = 0;
   if (e->pending) {  // the short last block (:203-222)
     int32_t st = enc_emit(e, e->pending, dst, cap, &w);
