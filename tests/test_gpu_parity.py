@@ -457,6 +457,39 @@ def test_encoder_structured_fuzz_vs_oracle(codec, oracle):
             assert np.array_equal(got, data)
 
 
+def test_encoder_sequence_shapes_vs_oracle(codec, oracle):
+    """Inputs built as (random literal run, copy of earlier bytes) pairs whose lengths sit on the
+    boundaries of the sequence format (_writeSequence / _writeLength, lib/src/block/lz4_block_encoder.dart:172-223):
+    14/15/16-byte runs, 269/270/271 and 524/525 (one, two, three length bytes), runs longer than a
+    wavefront and longer than the encoder's input window, copies of 4, 18/19/20, 273/274 and thousands
+    of bytes, many more sequences than one write batch holds.  Bytes identical to the oracle."""
+    import torch
+    rng = np.random.default_rng(31)
+    lits = [0, 1, 14, 15, 16, 63, 64, 65, 127, 128, 200, 201, 269, 270, 271, 524, 525, 780, 5000, 9000]
+    copies = [4, 5, 18, 19, 20, 64, 273, 274, 528, 529, 3000, 9000]
+    blocks = []
+    for blk in range(12):
+        a = bytearray(rng.integers(0, 256, size=300, dtype=np.uint8).tobytes())
+        while len(a) < 200000:
+            nl = int(rng.choice(lits)); nc = int(rng.choice(copies))
+            a += rng.integers(0, 256, size=nl, dtype=np.uint8).tobytes()
+            back = int(rng.integers(1, min(len(a), 65535) + 1))
+            for k in range(nc):  # byte-serial so that short distances give overlapping copies
+                a.append(a[len(a) - back])
+        blocks.append(bytes(a[:196608]))
+    for block, accel, d in ((65536, 1, None), (196608, 1, None), (65536, 3, blocks[0][:30000])):
+        data = np.frombuffer(b"".join(blocks), dtype=np.uint8)
+        src = torch.tensor(data, device="cuda")
+        d_t = torch.tensor(np.frombuffer(d, dtype=np.uint8).copy(), device="cuda") if d else None
+        slots, sizes, status = codec.compress_blocks(src, block, acceleration=accel, dictionary=d_t)
+        assert int(status.abs().sum()) == 0
+        h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+        for b in range(h_sizes.size):
+            ref = oracle.block_compress_fast(data[b * block:(b + 1) * block].tobytes(), acceleration=accel, dictionary=d)
+            assert int(h_sizes[b]) == len(ref), (block, b)
+            assert h_slots[b, : len(ref)].tobytes() == ref, (block, b)
+
+
 def test_encoder_with_dictionary_vs_oracle(lz, oracle):
     text = corpus_block(3).tobytes()
     d32k = text[:32768]
