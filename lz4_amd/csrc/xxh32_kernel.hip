@@ -158,8 +158,39 @@ __global__ __launch_bounds__(64) void xxh32_stripes_kernel(const uint8_t *data, 
   if (lane < 4) state[acc] = v;
 }
 
+// Few blocks (large ones, as a rule: a frame of 4 MiB blocks has 256 per GiB): a wavefront per block,
+// each hashing its block the way the single-stream kernel does (64 lanes fetch ahead into LDS, four
+// lanes run the chains).  Sixteen blocks to a wavefront would leave most of the chip idle and every
+// lane waiting out its own memory latency.
+__global__ __launch_bounds__(256) void xxh32_batch_wide_kernel(BatchArgs a, uint32_t *hash_out) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_y[4][kXChunk / 4];
+  const uint32_t lane = lane_id();
+  const uint32_t w = uni(threadIdx.x / kWave);
+  const uint32_t b = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  if (b >= a.nblocks) return;
+  const uint8_t *p = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+  const uint32_t len = uni(block_src_len(a, b));
+  const uint32_t acc = lane & 3;
+  uint32_t h;
+  if (len >= 16) {
+    uint32_t v = xxh_stream_rounds(xxh_init_acc(acc, 0), p, len / 16, s_y[w], lane, acc);
+    h = xxh_merge4(lane < 4 ? v : 0u, acc, lane);
+  } else {
+    h = XP5;  // seed 0
+  }
+  if (lane == 0) {
+    h += len;
+    const uint32_t done = len & ~15u;
+    hash_out[b] = xxh_finish(h, p + done, len - done);
+  }
+}
+
 void launch_xxh32_batch(const BatchArgs &a, uint32_t *d_hash, hipStream_t s) {
   if (a.nblocks == 0) return;
+  if (a.nblocks <= 2048) {
+    hipLaunchKernelGGL(xxh32_batch_wide_kernel, dim3((a.nblocks + 3) / 4), dim3(256), 0, s, a, d_hash);
+    return;
+  }
   uint32_t waves = (a.nblocks + 15) / 16;
   hipLaunchKernelGGL(xxh32_batch_kernel, dim3((waves + 3) / 4), dim3(256), 0, s, a, d_hash);
 }

@@ -60,10 +60,12 @@ def test_xxh32_lengths_vs_oracle(lz, oracle):
             assert lz.xxh32(d, seed) == oracle.xxh32(d, seed), n
 
 
-def test_xxh32_batch_vs_oracle(codec, oracle):
+@pytest.mark.parametrize("repeat", [3, 160])  # 48 blocks: a wavefront per block; 2560: sixteen blocks per wavefront
+def test_xxh32_batch_vs_oracle(codec, oracle, repeat):
     import torch
     rng = np.random.default_rng(4)
-    lens = [0, 1, 3, 15, 16, 17, 31, 32, 33, 100, 255, 4096, 65536, 65537, 7, 64] * 3
+    lens = [0, 1, 3, 15, 16, 17, 31, 32, 33, 100, 255, 4096, 65536 if repeat == 3 else 4111, 65537 if repeat == 3 else 8193,
+            7, 64] * repeat
     offs, blob, pos = [], bytearray(), 0
     for n in lens:
         pos += int(rng.integers(0, 7))  # arbitrary alignment
