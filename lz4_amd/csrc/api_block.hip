@@ -206,7 +206,7 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
   uint32_t *order_cnt = c->d_counters + kCounterOrder;
   LZ4MI_HIP(c, hipMemsetAsync(order_cnt, 0, 2 * sizeof(uint32_t), c->stream));
   LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
-  launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, getenv("LZ4MI_NO_ORDER") ? nullptr : c->order.as<uint32_t>(),
+  launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, c->order.as<uint32_t>(),
                 wave_grid(c, a.nblocks, 20), c->stream);  // 20 wavefronts per CU are resident (8 KiB of LDS each)
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
