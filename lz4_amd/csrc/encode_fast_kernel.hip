@@ -48,9 +48,9 @@ __device__ unsigned long long g_enc_span[2 * 65536];  // per block: start and en
 constexpr uint32_t kWinBytes = LZ4MI_WIN, kWinMask = kWinBytes - 1, kSeg = 1024, kWinPad = 16;
 constexpr uint32_t kClaimSlots = 256;  // LDS dwords per wavefront for the same-bucket vote of the re-hash
 #ifndef LZ4MI_FIRST
-#define LZ4MI_FIRST 8
+#define LZ4MI_FIRST 10
 #endif
-constexpr uint32_t kFirst = LZ4MI_FIRST;  // probes of a run evaluated in the first step (16 was measured slower: twice the table gather for the ~20 % of runs that need it)
+constexpr uint32_t kFirst = LZ4MI_FIRST;  // probes of a run evaluated in the first step (bench encode launch: 8 -> 2.74-2.79 ms, 9-11 -> 2.69-2.73, 16 and 4 clearly slower)
 constexpr uint32_t kLead = kFirst > 8 ? 1024 : 640;  // an iteration may read ring bytes up to anchor + kLead
 
 struct __attribute__((packed)) P32 { uint32_t v; };
