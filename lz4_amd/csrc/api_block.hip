@@ -207,7 +207,7 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
   LZ4MI_HIP(c, hipMemsetAsync(order_cnt, 0, 2 * sizeof(uint32_t), c->stream));
   LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
   launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, c->order.as<uint32_t>(),
-                wave_grid(c, a.nblocks, 20), c->stream);  // LDS holds 20 wavefronts per CU (registers 16); 12 to 32 measured, 20 best
+                wave_grid(c, a.nblocks, 16), c->stream);  // 16 wavefronts per CU are resident (registers); a wavefront that is not would hold its first block back
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
 }

@@ -557,8 +557,10 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
   // are handed out through the queue.
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
   const bool direct = a.nblocks <= nwaves;
-  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(counter, lane);
-  for (;; b = direct ? 0xffffffffu : next_block(counter, lane)) {
+  // a wavefront's first block is its own index (thousands of wavefronts popping one queue head at
+  // launch serialise on it); the queue hands out the blocks behind those
+  uint32_t b = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  for (;; b = direct ? 0xffffffffu : nwaves + next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
     const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);

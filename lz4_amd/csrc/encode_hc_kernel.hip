@@ -396,8 +396,10 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcS
   // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
   const bool direct = ka->a.nblocks <= nwaves;
-  uint32_t b = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave) : next_block(ka->counter, lane);
-  for (;; b = direct ? 0xffffffffu : next_block(ka->counter, lane)) {
+  // a wavefront's first block is its own index (thousands of wavefronts popping one queue head at
+  // launch serialise on it); the queue hands out the blocks behind those
+  uint32_t b = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  for (;; b = direct ? 0xffffffffu : nwaves + next_block(ka->counter, lane)) {
     if (b >= ka->a.nblocks) break;
     EncIn in;
     in.dict = ka->a.dict;
