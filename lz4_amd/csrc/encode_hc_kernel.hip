@@ -111,11 +111,7 @@ __device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x
     for (uint32_t u = 0; u < U; u++) v[u] = xld(x.cnt + k + u * kWave + lane);
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
-      uint32_t inc = v[u];
-      for (uint32_t d = 1; d < kWave; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, (int)d);
-        if (lane >= d) inc += o;
-      }
+      const uint32_t inc = wave_incl_scan(v[u]);
       xst(x.floor_ + k + u * kWave + lane, carry + inc - v[u]);
       xst(x.cnt + k + u * kWave + lane, 0u);
       carry += rdlane(inc, kWave - 1);
