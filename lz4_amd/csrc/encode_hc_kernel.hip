@@ -33,7 +33,7 @@ struct HcIndex {
   uint32_t *cnt;     // 65536 bucket counters, all zero between blocks
   uint32_t *floor_;  // 65536: lowest rank of the bucket a walk can still reach
   uint32_t *rank;    // per position of dict||src
-  uint32_t *sorted;  // per rank: position (| kNoIns)
+  uint2 *sorted;     // per rank: position (| kNoIns) and the four bytes at that position (what a walk compares first)
 };
 
 // Arrays of a slot are rewritten for every block by the wavefront that owns the slot; workgroup
@@ -44,6 +44,15 @@ __device__ __forceinline__ uint32_t xld(const uint32_t *p) {
 __device__ __forceinline__ void xst(uint32_t *p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// index entry: both words in one access
+__device__ __forceinline__ uint2 xld_entry(const uint2 *p) {
+  const unsigned long long v = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ void xst_entry(uint2 *p, uint32_t pos, uint32_t seq) {
+  __hip_atomic_store((unsigned long long *)p, ((unsigned long long)seq << 32) | pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void xst_entry_pos(uint2 *p, uint32_t pos) { xst((uint32_t *)p, pos); }
 
 // lanes (among the valid ones) whose 16-bit hash equals this lane's
 __device__ __forceinline__ uint64_t same_bucket(uint32_t h, bool valid) {
@@ -119,11 +128,12 @@ __device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x
   }
   // 3: scatter
   for (uint32_t base = 0; base < T; base += U * kWave) {
-    uint32_t h[U], ord[U];
+    uint32_t h[U], ord[U], sq[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
       const uint32_t p = base + u * kWave + lane;
-      h[u] = p < T ? hash16(in_ld32<HAS_DICT>(in, p)) : 0u;
+      sq[u] = p < T ? in_ld32<HAS_DICT>(in, p) : 0u;
+      h[u] = hash16(sq[u]);
       ord[u] = p < T ? xld(x.rank + p) : 0u;
     }
     uint32_t st[U];
@@ -133,7 +143,7 @@ __device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x
     for (uint32_t u = 0; u < U; u++) {
       const uint32_t p = base + u * kWave + lane;
       if (p < T) {
-        xst(x.sorted + st[u] + ord[u], p);
+        xst_entry(x.sorted + st[u] + ord[u], p, sq[u]);
         xst(x.rank + p, st[u] + ord[u]);
       }
     }
@@ -141,7 +151,7 @@ __device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x
   // the last three dictionary positions are never inserted (:105-109 stops at dictLength - 4)
   if (HAS_DICT && D != 0) {
     const uint32_t q = D - 1 - lane;
-    if (lane < 3 && lane < D && q < T) xst(x.sorted + xld(x.rank + q), q | kNoIns);
+    if (lane < 3 && lane < D && q < T) xst_entry_pos(x.sorted + xld(x.rank + q), q | kNoIns);
   }
 }
 
@@ -225,15 +235,16 @@ __device__ __forceinline__ void hc_eval_slice(const EncIn &in, const HcIndex &x,
                                               uint32_t lane, uint32_t &best_len, uint32_t &best_ref) {
   while (idx >= lo && depth < max_depth) {
     const int32_t my = idx - (int32_t)lane;
-    const uint32_t e = my >= lo ? xld(x.sorted + my) : kNoIns;
+    uint2 en = make_uint2(kNoIns, 0u);
+    if (my >= lo) en = xld_entry(x.sorted + my);
+    const uint32_t e = en.x;
     const bool ins = !(e & kNoIns);
     const uint64_t insm = ballot(ins);
     const uint32_t ordinal = (uint32_t)__builtin_popcountll(insm & ((1ull << lane) - 1ull));
     const bool take = ins && depth + ordinal < max_depth;  // :123 depth bound, flagged entries are not on the chain
     const uint32_t c = e & kPosMask;
     const bool near = take && P - c <= 0xFFFFu;  // :125-129
-    const uint32_t cseq = near ? in_ld32<HAS_DICT>(in, c) : 0u;
-    const bool m4 = near && cseq == seq;
+    const bool m4 = near && en.y == seq;
     uint32_t ml = 0;
     bool more = false;
     if (m4) ml = hc_lane_len<HAS_DICT>(in, P, c, total, 512u, more);
@@ -299,16 +310,16 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
           continue;
         }
         // one candidate per walking lane
-        uint32_t e = kNoIns;
+        uint2 en = make_uint2(kNoIns, 0u);
         if (act) {
-          e = xld(x.sorted + idx);
+          en = xld_entry(x.sorted + idx);
           idx--;
         }
+        const uint32_t e = en.x;
         const bool cnd = act && !(e & kNoIns);  // flagged entries are not on the chain
         const uint32_t c = e & kPosMask;
         const bool near = cnd && p - c <= 0xFFFFu;  // far candidates only consume depth (:125-129)
-        const uint32_t cseq = near ? in_ld32<HAS_DICT>(in, c) : 0u;
-        bool m4 = near && cseq == seq;
+        bool m4 = near && en.y == seq;
         // a lane with a 4-byte hit holds a match: lanes above the lowest such lane no longer matter
         const uint64_t hitm = ballot(m4);
         if (hitm) {
@@ -360,7 +371,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
       // the last three positions of the match are never inserted
       {
         const uint32_t q = i - 3 + lane;
-        if (lane < 3 && q + 4 <= total) xst(x.sorted + xld(x.rank + q), q | kNoIns);
+        if (lane < 3 && q + 4 <= total) xst_entry_pos(x.sorted + xld(x.rank + q), q | kNoIns);
       }
     }
   }
@@ -373,7 +384,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
 struct HcScratch {
   uint32_t *cnt;       // nslots * 65536, zero
   uint32_t *floor_;    // nslots * 65536
-  uint32_t *index;     // nslots * 2 * stride: rank[stride], sorted[stride]
+  uint32_t *index;     // nslots * 3 * stride words: rank[stride], sorted[stride] (two words per entry)
   uint64_t stride;     // positions per slot
 };
 
@@ -396,8 +407,8 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcS
   HcIndex x;
   x.cnt = ka->sc.cnt + (size_t)slot * kHashEntries;
   x.floor_ = ka->sc.floor_ + (size_t)slot * kHashEntries;
-  x.rank = ka->sc.index + (size_t)slot * 2 * stride;
-  x.sorted = x.rank + stride;
+  x.rank = ka->sc.index + (size_t)slot * 3 * stride;
+  x.sorted = (uint2 *)(x.rank + stride);
   const uint32_t max_depth = ka->max_depth;
   // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
@@ -455,7 +466,7 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
   const uint64_t budget = 8ull << 30;  // bytes of index scratch
   uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);
-  while (slots > 4 && (uint64_t)slots * stride * 8 > budget) slots -= 4;
+  while (slots > 4 && (uint64_t)slots * stride * 12 > budget) slots -= 4;
   const size_t tbl = (size_t)slots * kHashEntries * sizeof(uint32_t);
   if (tbl > c->hc_cnt.cap) {  // counters must start at zero; the kernel leaves them at zero
     LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
@@ -463,7 +474,7 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
     LZ4MI_HIP(c, hipMemsetAsync(c->hc_cnt.p, 0, c->hc_cnt.cap, c->stream));
   }
   LZ4MI_HIP(c, c->hc_floor.ensure(tbl));
-  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 8));
+  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 12));
   HcScratch sc;
   sc.cnt = c->hc_cnt.as<uint32_t>();
   sc.floor_ = c->hc_floor.as<uint32_t>();
