@@ -202,9 +202,11 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
   // words kCounterDecode, +1 (queue heads of the two decode kernels) and +2 (length of the redo list)
   uint32_t *counter = c->d_counters + kCounterDecode;
   LZ4MI_HIP(c, c->redo.ensure((size_t)a.nblocks * 16));
-  LZ4MI_HIP(c, hipMemsetAsync(counter, 0, 3 * sizeof(uint32_t), c->stream));
   uint32_t *order_cnt = c->d_counters + kCounterOrder;
-  LZ4MI_HIP(c, hipMemsetAsync(order_cnt, 0, 2 * sizeof(uint32_t), c->stream));
+  // one fill for the decode words and the order words (the encoders' words in between are zeroed by
+  // their own launches before use; everything runs on the context's one stream)
+  static_assert(kCounterDecode == 0 && kCounterOrder + 2 <= kNumCounters, "counter layout");
+  LZ4MI_HIP(c, hipMemsetAsync(c->d_counters, 0, (kCounterOrder + 2) * sizeof(uint32_t), c->stream));
   LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
   launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, c->order.as<uint32_t>(),
                 wave_grid(c, a.nblocks, 16), c->stream);  // 16 wavefronts per CU are resident (registers); a wavefront that is not would hold its first block back
