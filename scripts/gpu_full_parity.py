@@ -9,7 +9,8 @@ from oracle import lz4ref
 from tools.corpus import corpus
 codec = DeviceCodec(0)
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
-for seed in (0, 7):
+SEEDS = [int(x) for x in sys.argv[2:]] or [0, 7]
+for seed in SEEDS:
     data = corpus(NB, seed=seed)
     src = torch.from_numpy(data).cuda()
     slots, sizes, st = codec.compress_blocks(src, 65536)
