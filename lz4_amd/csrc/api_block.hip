@@ -112,7 +112,7 @@ extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   DevBuf *bufs[] = {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
                     &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
                     &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
-                    &c->hc_chain, &c->hc_cnt, &c->hc_floor, &c->redo, &c->order};
+                    &c->hc_chain, &c->hc_cnt, &c->hc_floor, &c->order};
   for (DevBuf *b : bufs) b->release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -138,12 +138,6 @@ int32_t pin_reserve(lz4mi_ctx *c, size_t n) {
   LZ4MI_HIP(c, hipHostMalloc(&c->h_pin, want, hipHostMallocDefault));
   c->h_pin_cap = want;
   return LZ4MI_OK;
-}
-
-static uint32_t wave_grid(lz4mi_ctx *c, uint32_t nblocks, uint32_t waves_per_cu) {
-  uint32_t groups = (nblocks + 3) / 4;
-  uint32_t cap = (uint32_t)c->cu_count * waves_per_cu / 4;
-  return groups < cap ? (groups ? groups : 1) : cap;
 }
 
 static int32_t ensure_slots(lz4mi_ctx *c, uint32_t want) {
@@ -199,17 +193,14 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
     a.dict += a.dict_len - 65536;
     a.dict_len = 65536;
   }
-  // words kCounterDecode, +1 (queue heads of the two decode kernels) and +2 (length of the redo list)
   uint32_t *counter = c->d_counters + kCounterDecode;
-  LZ4MI_HIP(c, c->redo.ensure((size_t)a.nblocks * 16));
   uint32_t *order_cnt = c->d_counters + kCounterOrder;
-  // one fill for the decode words and the order words (the encoders' words in between are zeroed by
+  // one fill for the decode word and the order words (the encoders' words in between are zeroed by
   // their own launches before use; everything runs on the context's one stream)
   static_assert(kCounterDecode == 0 && kCounterOrder + 2 <= kNumCounters, "counter layout");
   LZ4MI_HIP(c, hipMemsetAsync(c->d_counters, 0, (kCounterOrder + 2) * sizeof(uint32_t), c->stream));
   LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
-  launch_decode(a, strict, counter, counter + 2, c->redo.p, order_cnt, c->order.as<uint32_t>(),
-                wave_grid(c, a.nblocks, 16), c->stream);  // 16 wavefronts per CU are resident (registers); a wavefront that is not would hold its first block back
+  launch_decode(a, strict, counter, order_cnt, c->order.as<uint32_t>(), (uint32_t)c->cu_count, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
 }

@@ -60,8 +60,6 @@ struct lz4mi_ctx {
       hashes, words, total;
   // HC encoder: per-slot position index (rank + sorted), bucket counters and floors
   lz4mi::DevBuf hc_chain, hc_cnt, hc_floor;
-  // decoder: blocks handed from the plain kernel to the group kernel (16 bytes per block)
-  lz4mi::DevBuf redo;
   // decoder: queue position -> block index of a launch (long blocks first)
   lz4mi::DevBuf order;
 

@@ -5,20 +5,22 @@
 // (lib/src/internal/byte_writer.dart:93-121) check for check, so the status of
 // a malformed block equals the exception the reference raises.
 //
-// Layout: the token stream is parsed wave-uniformly out of a 1 KiB register window of the
-// compressed block (four dwords per lane, fetched with one coalesced load and read back with
-// v_readlane); a refill of that window is the only point where the parse waits on memory.
-// Short literal runs are taken from the same registers (ds_bpermute), and the most recent
-// 8 KiB of output are mirrored in an LDS ring per wavefront, so a short match whose source is
-// recent is served from LDS: a typical sequence needs no memory round trip at all, only stores.
-// That matters because loads, stores and atomics of a wavefront retire through one in-order
-// counter on gfx950: any load issued behind output stores waits for all of them.  Paths that
-// do load (far matches, long runs, window refills) end with an explicit vmcnt(0) so that the
-// compiler's wait insertion never adds a drain of its own to the load-free paths.
-// Long runs go memory to memory with 16-byte aligned stores (1 KiB per wave-instruction);
-// matches that overlap their own output replicate the period with a modulo gather.
-// Blocks that consist of short sequences (text-like data: ten bytes per sequence) are put down
-// by the first kernel and finished by a second one that decodes about ten sequences per step.
+// Two loops share a block.
+//
+// The batch loop takes up to 64 sequences at a time.  The compressed bytes sit in an LDS window;
+// every lane parses the byte it stands on as if it were a token (lengths with up to two extension
+// bytes, offset, where the next token would start), and the chain of real token starts is followed
+// with one cross-lane read per sequence.  After that lane j owns sequence j: a prefix sum places
+// all sequences in the output, the reference's checks are evaluated for all of them at once, and
+// the copies run out of and into an LDS ring that mirrors the most recent output: literals lane
+// by lane, matches one after the other with the whole wavefront (LDS operations of a wavefront
+// execute in order, so a match sees everything written before it), matches older than the ring
+// four at a time out of memory.  The ring is written to memory in aligned 16-byte pieces once per
+// batch.  A sequence that does not fit this scheme (three or more length-extension bytes, the
+// last sequence of a block, anything that fails a check) ends the batch in front of it.
+//
+// The general loop (decode_run) takes such a sequence on its own, straight from and to memory,
+// in the reference's order of checks, and is where every block ends: all status codes come from it.
 #include "device_common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -177,46 +179,19 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   vm_quiesce();
 }
 
-__device__ __forceinline__ uint32_t lane_pull(uint32_t v, uint32_t from) {
-  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v);
-}
+constexpr uint32_t kRing = 8192;   // bytes of recent output the general loop mirrors in LDS
+constexpr uint32_t kShort = 256;   // copies up to this length go through its ring path
 
-#ifndef LZ4MI_MS_ENTER
-#define LZ4MI_MS_ENTER 64
-#endif
-#ifndef LZ4MI_MS_MIN
-#define LZ4MI_MS_MIN 3
-#endif
-constexpr uint32_t kMsEnter = LZ4MI_MS_ENTER;  // short sequences in a row before the first kernel puts a block down
-constexpr uint32_t kMsBytes = 20;              // output bytes per sequence below which a block counts as short-sequence
-constexpr uint32_t kMsPenalty = 8;             // what a sequence with a length extension takes off the score
-constexpr uint32_t kMsReenter = 8;             // the same inside the second kernel, where changing loops is cheap
-constexpr uint32_t kMsTry = 1;                 // GROUPS: short sequences in a row before the next try
-constexpr uint32_t kMsLeave = 16;              // GROUPS: single sequences in a row before handing back
-constexpr uint32_t kMsMin = LZ4MI_MS_MIN;      // smallest group worth giving up the ring for
-
-#ifndef LZ4MI_RING
-#define LZ4MI_RING 8192
-#endif
-constexpr uint32_t kRing = LZ4MI_RING;   // bytes of recent output mirrored in LDS per wavefront
-constexpr uint32_t kShort = 256;   // copies up to this length go through the ring path
-
-// Decodes one block with the whole wave into dst[op_start ...).  `cap` is
-// decompressedSize (STRICT) or the ByteWriter maxLength minus the pre-filled prefix
-// (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
-// non-negative positions come from dst itself (earlier blocks of a linked frame),
-// negative positions from the tail of `prefix` (dictionary).  out_len = bytes written.
-//
-// The loop exists in two variants that hand a block back and forth at sequence boundaries, each
-// starting from fresh window/ring state as if the rest of the block were a block of its own:
-// GROUPS == false takes one sequence per iteration and, when HANDOVER is nonzero, returns
-// kSwitchRun once its short-sequence score (+1 for a sequence without length extensions,
-// -kMsPenalty for any other) reaches HANDOVER; GROUPS == true tries whole groups of short
-// sequences first (see below) and returns kSwitchRun once kMsLeave sequences in a row had to go
-// one by one.  (With the group code inside the only loop of the only kernel, long-match data
-// decoded 5-9 % slower; the first kernel of a launch therefore contains the plain loop alone.)
-constexpr int32_t kSwitchRun = -1;  // not a status: continue with the other variant at in_used / out_len
-template <bool STRICT, bool HAS_PREFIX, bool GROUPS, uint32_t HANDOVER>
+// ---------------------------------------------------------------------------------------------
+// General loop: one sequence per iteration, every check in the reference's order.  Decodes into
+// dst[op_start ...).  `cap` is decompressedSize (STRICT) or the ByteWriter maxLength minus the
+// pre-filled prefix (lenient).  A match may reach `back_limit` bytes before op_start: bytes at
+// non-negative positions come from dst itself (earlier output), negative positions from the tail
+// of `prefix` (dictionary).  Starts from fresh window/ring state, as if the rest of the block
+// were a block of its own.  With ONE it returns kSwitchRun after one complete sequence (literals
+// and match); in_used / out_len say how far it got.
+constexpr int32_t kSwitchRun = -1;  // not a status: the block goes on at in_used / out_len
+template <bool STRICT, bool HAS_PREFIX, bool ONE>
 __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                               const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                               const uint8_t *__restrict__ prefix, uint32_t prefix_len,
@@ -231,15 +206,11 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
   sm.sp = 0xffffff00u;
   sm.S = 0;
 
-  uint32_t ip = 0, op = 0;  // op counts bytes written by this block
-  uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this block
-  uint32_t nseq = 0, mark = 0;  // plain loop with HANDOVER: sequences seen, op at the last check
-  uint32_t shorts = 0;      // score: +1 per sequence without length extensions, -kMsPenalty per other one
-  uint32_t idle = 0;        // GROUPS: sequences taken one by one since the last group
+  uint32_t ip = 0, op = 0;  // op counts bytes written by this call
+  uint32_t rlo = 0;         // the ring mirrors output positions [rlo, op) of this call
   const uint32_t in_end = src_len;
   int32_t st = LZ4MI_OK;
   uint8_t *const out = dst + op_start;
-  PH_DECL
 
   for (;;) {
     if (STRICT) {
@@ -251,21 +222,8 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
     } else {
       if (ip >= in_end) break;  // :86-88
     }
-    if (!GROUPS && HANDOVER) {
-      // every HANDOVER (a power of two) sequences: fewer than kMsBytes output bytes per sequence
-      // over that stretch means short sequences
-      if ((++nseq & (HANDOVER - 1u)) == 0u) {
-        if (op - mark < HANDOVER * kMsBytes) { st = kSwitchRun; break; }
-        mark = op;
-        // a long block decides when the launch ends: it takes issue priority over its neighbours
-        if (nseq == 64) __builtin_amdgcn_s_setprio(1);
-        if (nseq == 192) __builtin_amdgcn_s_setprio(2);
-        if (nseq == 448) __builtin_amdgcn_s_setprio(3);
-      }
-    }
     uint32_t token = sbyte(w, sm, ip, lane);
     ip++;
-    const bool shortseq = (token & 0xF0u) != 0xF0u && (token & 15u) != 15u;  // no length extensions
     uint64_t lit64 = token >> 4;
     if (lit64 == 15) {
       if (!read_ext(w, sm, ip, in_end, lit64, lane)) { st = LZ4MI_FORMAT_EOF; break; }
@@ -275,7 +233,6 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
       if (lit64 > (uint64_t)(in_end - ip)) { st = LZ4MI_FORMAT_EOF; break; }  // readBytesView
       if (!STRICT && lit64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; } // writer maxLength
       const uint32_t lit = (uint32_t)lit64;
-      PH(0);
       if (ip - sm.sp + lit <= kWave) {
         // the whole run is in the stream register: lanes [rel, rel + lit) store their byte
         const uint32_t rel = ip - sm.sp;
@@ -285,7 +242,6 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
           ring[(op + k) & (kRing - 1)] = (uint8_t)sm.S;
         }
         if (op + lit > rlo + kRing) rlo = op + lit - kRing;
-        PH(1); PH_CNT(8);
       } else if (lit <= kShort) {
         // short run: 64 bytes per step out of the register window; the last gather also holds the
         // bytes that follow the run and becomes the stream register
@@ -302,12 +258,10 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         sm.sp = ip + k0 - kWave;
         sm.S = v;
         if (op + lit > rlo + kRing) rlo = op + lit - kRing;
-        PH(1); PH_CNT(14);
       } else {
         wave_copy(out + op, src + ip, lit, lane);
         vm_quiesce();
         rlo = op + lit;  // ring holds nothing older than this
-        PH(2); PH_CNT(9);
       }
       ip += lit;
       op += lit;
@@ -332,7 +286,6 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
     if (dist == 0 || (uint64_t)dist > (uint64_t)op + back_limit) { st = LZ4MI_CORRUPT_DISTANCE; break; }
     if (!STRICT && ml64 > (uint64_t)(cap - op)) { st = LZ4MI_LIMIT; break; }
     const uint32_t ml = (uint32_t)ml64;
-    PH(6);
     if (ml <= kShort) {
       // byte-serial copy semantics (byte_writer.dart:116-118): source byte of output k is
       // k mod dist bytes into the period that ends at op
@@ -371,195 +324,430 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         vm_quiesce();
       }
       rlo = (uint32_t)ring_from;
-      if (s >= ring_from) { PH(3); PH_CNT(10); } else { PH(4); PH_CNT(11); }
     } else {
       copy_match<HAS_PREFIX>(dst, op_start + op, dist, ml, prefix, prefix_len, lane);
       rlo = op + ml;
-      PH(5); PH_CNT(13);
     }
     op += ml;
-    if (!GROUPS) continue;
-    shorts = shortseq ? shorts + 1u : (shorts > kMsPenalty ? shorts - kMsPenalty : 0u);
-    if (++idle > kMsLeave && ip < in_end && op < cap) { st = kSwitchRun; break; }
-    while (shorts >= kMsTry && ip < in_end && op < cap) {  // else the checks at the top decide
-      // ---- several short sequences at once.  Data made of short sequences (text) spends its time
-      // on per-sequence latency, above all the load of a match source that is older than the ring.
-      // Here every lane parses the byte it holds as if it were a token; following the chain of
-      // real token starts from lane 0 is a handful of scalar steps; a prefix sum places every
-      // sequence in the output; then all literal bytes of the group go out in one store, all match
-      // sources are fetched with one round trip and all matches are written together.  A sequence
-      // joins the group only if it has no length extension, is not the last of the block, passes
-      // the reference's checks, and its source lies wholly in output written before the group
-      // (18 bytes from the source start, so the fixed-size fetch never reads ahead of the data);
-      // the first sequence that does not qualify ends the group and goes through the general path.
-      if (sm.sp != ip) stream_load(w, sm, ip, lane);
-      const uint32_t avail_in = in_end - ip;
-      const uint32_t ll = sm.S >> 4, ml = (sm.S & 15u) + 4u;
-      const uint32_t nx = lane + 3u + ll;  // where the next token would start
-      const uint32_t off = lane_pull(sm.S, lane + 1u + ll) | (lane_pull(sm.S, lane + 2u + ll) << 8);
-      const bool ok = ll < 15u && ml < 19u && nx <= kWave && nx < avail_in && off != 0u;
-      const uint64_t okm = ballot(ok);
-      uint64_t starts = 0;
-      uint32_t r = 0;
-      while (r < kWave && ((okm >> r) & 1ull)) {
-        starts |= 1ull << r;
-        r = rdlane(nx, r);
-      }
-      if (starts) {
-        bool is_start = (starts >> lane) & 1ull;
-        const uint32_t mine = is_start ? ll + ml : 0u;
-        const uint32_t incl = wave_incl_scan(mine);
-        const uint32_t excl = incl - mine;
-        const uint32_t mrel = excl + ll;  // match position relative to op
-        const int64_t srcpos = (int64_t)op_start + op + mrel - off;
-        const bool bad = is_start && ((uint64_t)off > (uint64_t)op + mrel + back_limit ||  // copyMatch's distance check
-                                      off < mrel + 18u || srcpos < 0);
-        const uint64_t bm = ballot(bad);
-        uint32_t total = rdlane(incl, kWave - 1);
-        if (bm) {
-          const uint32_t v = (uint32_t)__builtin_ctzll(bm);
-          starts &= (1ull << v) - 1ull;
-          r = v;
-          total = rdlane(excl, v);
-          is_start = (starts >> lane) & 1ull;
-        }
-        if ((uint32_t)__builtin_popcountll(starts) >= kMsMin && total <= cap - op) {
-          uint64_t v0 = 0, v1 = 0;
-          uint32_t v2 = 0;
-          if (is_start) {  // sources first: they queue behind the previous group's stores only
-            const uint8_t *sp8 = dst + srcpos;
-            v0 = ld64(sp8);
-            v1 = ld64(sp8 + 8);
-            v2 = ld16(sp8 + 16);
-          }
-          {  // every literal byte of the group: lane j belongs to the nearest start at or below it
-            const uint64_t below = starts & (~0ull >> (63u - lane));
-            const uint32_t k = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-            const uint32_t llk = lane_pull(ll, k), exk = lane_pull(excl, k);
-            const uint32_t li = lane - k - 1u;
-            if (lane < r && li < llk) out[op + exk + li] = (uint8_t)sm.S;
-          }
-          if (is_start) {
-            uint8_t *d = out + op + mrel;
-            if (ml >= 16u) {
-              st64(d, v0);
-              st64(d + 8, v1);
-              if (ml == 18u) st16(d + 16, v2);
-              if (ml == 17u) d[16] = (uint8_t)v2;
-            } else {
-              uint64_t cur = v0;
-              if (ml & 8u) { st64(d, v0); d += 8; cur = v1; }
-              if (ml & 4u) { st32(d, (uint32_t)cur); d += 4; cur >>= 32; }
-              if (ml & 2u) { st16(d, (uint32_t)cur); d += 2; cur >>= 16; }
-              if (ml & 1u) d[0] = (uint8_t)cur;
-            }
-          }
-          ip += r;
-          op += total;
-          rlo = op;  // the ring holds nothing of this group
-          idle = 0;
-          continue;
-        }
-      }
-      shorts = 0;
-    }
+    if (ONE) { st = kSwitchRun; break; }
   }
-  PH(0);
-  PH_FLUSH(g_dec_phase, lane);
   in_used = ip;
   out_len = op;
   return st;
 }
 
-template <bool STRICT, bool HAS_PREFIX, bool ALLOW_GROUPS>
+// ---------------------------------------------------------------------------------------------
+// Batch loop.
+#ifndef LZ4MI_STG
+#define LZ4MI_STG 8192
+#endif
+constexpr uint32_t kStg = LZ4MI_STG;       // LDS ring of recent output per wavefront (>= kRing: the general loop borrows it)
+constexpr uint32_t kStgMask = kStg - 1;
+constexpr uint32_t kStgPad = 16;           // behind the ring: catches the tail of a dword written across the wrap
+constexpr uint32_t kBatchOut = kStg / 2;   // most output bytes of one batch; the other half is history
+constexpr uint32_t kCw = 2048;             // compressed window in LDS
+constexpr uint32_t kCwPad = 16;
+constexpr uint32_t kCwTop = kCw + kCwPad - 4;  // highest offset a 4-byte read may start at
+constexpr uint32_t kLenMax = 15 + 255 + 254;   // longest literal run (match: + 4) with two extension bytes
+constexpr uint32_t kSeqIn = 1 + 2 + kLenMax + 2 + 2 + 4;  // compressed bytes one batched sequence may span, plus slack
+constexpr uint32_t kFarMax = 320;          // longest match the out-of-ring path fetches (5 steps of 64 bytes)
+static_assert(kStg >= kRing, "the general loop uses the first kRing bytes of the staging ring");
+
+struct __attribute__((packed)) DP32 { uint32_t v; };
+typedef __attribute__((address_space(3))) DP32 lds_dp32;
+
+// four bytes at window offset a (clamped: a read past the window returns bytes that no caller uses)
+__device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
+  a = a < kCwTop ? a : kCwTop;
+  return ((const lds_dp32 *)(cw + a))->v;
+}
+__device__ __forceinline__ uint32_t cw8(const lds_u8 *cw, uint32_t a) {
+  a = a < kCwTop + 3 ? a : kCwTop + 3;
+  return cw[a];
+}
+
+// Parses the byte at window offset a as a token.  ok: the sequence has at most two extension bytes per
+// length and its header lies inside the first wlim bytes of the window (with up to two bytes of
+// slack), so every field read here is real.  cplx: a third extension byte would be needed.
+struct SeqFields {
+  uint32_t ll, ls, ml, dist, nx;  // literal length, window offset of the literals, match length, offset, next token
+  bool ok, cplx;
+};
+__device__ __forceinline__ SeqFields spec_parse(const lds_u8 *cw, uint32_t a, uint32_t wlim) {
+  SeqFields f;
+  const uint32_t t4 = cw32(cw, a);
+  const uint32_t tok = t4 & 255u, e1 = (t4 >> 8) & 255u, e2 = (t4 >> 16) & 255u;
+  uint32_t ll = tok >> 4, xl = 0;
+  bool cplx = false;
+  if (ll == 15u) {
+    ll += e1;
+    xl = 1;
+    if (e1 == 255u) {
+      ll += e2;
+      xl = 2;
+      cplx = e2 == 255u;
+    }
+  }
+  f.ll = ll;
+  f.ls = a + 1u + xl;
+  const uint32_t q = f.ls + ll;
+  const uint32_t o4 = cw32(cw, q);
+  f.dist = o4 & 0xffffu;
+  const uint32_t f1 = (o4 >> 16) & 255u, f2 = o4 >> 24;
+  const uint32_t mc = tok & 15u;
+  uint32_t ml = mc + 4u, xm = 0;
+  if (mc == 15u) {
+    ml += f1;
+    xm = 1;
+    if (f1 == 255u) {
+      ml += f2;
+      xm = 2;
+      cplx = cplx || f2 == 255u;
+    }
+  }
+  f.ml = ml;
+  f.nx = q + 2u + xm;
+  f.cplx = cplx;
+  f.ok = !cplx && q + 4u <= wlim;
+  return f;
+}
+
+// Loads kCw bytes of the block, starting at the 16-byte aligned address at or below src + ip, into the
+// window.  wb = compressed offset of window byte 0 (may be negative by up to 15), wlim = valid bytes.
+__device__ __forceinline__ void cw_load(lds_u8 *cw, const uint8_t *__restrict__ src, uint32_t in_end, uint32_t ip,
+                                        uint32_t lane, int32_t &wb, uint32_t &wlim) {
+  const uint32_t mis = (uint32_t)((uintptr_t)(src + ip) & 15u);
+  wb = (int32_t)ip - (int32_t)mis;
+  const uint8_t *g = src + wb;
+  const uint32_t avail = in_end - (uint32_t)wb;
+  wlim = avail < kCw ? avail : kCw;
+  u32x4 v[kCw / 1024];
+#pragma unroll
+  for (uint32_t k = 0; k < kCw / 1024; k++) {
+    const uint32_t o = 1024u * k + 16u * lane;
+    v[k] = u32x4{0, 0, 0, 0};
+    if (o < wlim) v[k] = *(const u32x4 *)(g + o);  // an aligned 16 bytes that hold at least one byte of the block
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < kCw / 1024; k++) *(lds_u128 *)(cw + 1024u * k + 16u * lane) = v[k];
+  vm_quiesce();
+}
+
+// lane mod d for d in 1..63 (exact: (lane + 0.5) / d is at least 1/128 away from every integer)
+__device__ __forceinline__ uint32_t lane_mod(uint32_t lane, uint32_t d) {
+  const float q = ((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)d);
+  return lane - (uint32_t)q * d;
+}
+
+// Writes output positions [from, to) of the ring to memory.  Positions are block-relative; the ring
+// index of position p is (p + goff) & kStgMask with goff = low four address bits of position 0, so a
+// 16-byte aligned piece of memory is a 16-byte aligned piece of the ring.  With `all` the range is
+// written to the last byte, otherwise up to the last 16-byte boundary (the rest follows with the
+// next batch).  Returns the new flushed-up-to position.
+__device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, uint32_t goff, uint32_t from, uint32_t to,
+                                              bool all, uint32_t lane) {
+  if (from >= to) return from;
+  const uint32_t head = (16u - ((from + goff) & 15u)) & 15u;
+  if (head) {
+    const uint32_t n = head < to - from ? head : to - from;
+    if (lane < n) out[from + lane] = stg[(from + goff + lane) & kStgMask];
+    from += n;
+  }
+  const uint32_t pieces = (to - from) >> 4;
+  for (uint32_t c0 = 0; c0 < pieces; c0 += 4 * kWave) {
+    u32x4 v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t c = c0 + u * kWave + lane;
+      v[u] = *(const lds_u128 *)(stg + ((from + goff + 16u * (c < pieces ? c : 0u)) & kStgMask));
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t c = c0 + u * kWave + lane;
+      if (c < pieces) *(u32x4 *)(out + from + 16u * c) = v[u];
+    }
+  }
+  from += 16u * pieces;
+  if (all && from < to) {
+    if (lane < to - from) out[from + lane] = stg[(from + goff + lane) & kStgMask];
+    from = to;
+  }
+  return from;
+}
+
+template <bool STRICT, bool HAS_PREFIX>
 __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                 const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                 const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                                lds_u8 *ring, uint32_t lane, uint32_t &out_len) {
-  if (!ALLOW_GROUPS) {  // the plain loop alone, start to end
-    uint32_t used = 0;
-    return decode_run<STRICT, HAS_PREFIX, false, 0>(src, src_len, dst, op_start, cap, back_limit, prefix,
-                                                        prefix_len, ring, lane, used, out_len);
-  }
+                                                lds_u8 *stg, lds_u8 *cw, uint32_t lane, uint32_t &out_len) {
+  const uint32_t in_end = src_len;
+  uint8_t *const out = dst + op_start;
+  const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
   uint32_t ip = 0, op = 0;
-  int32_t st;
-  for (bool groups = true;; groups = !groups) {  // callers come here because short sequences were seen
+  uint32_t fl = 0;   // output in front of this position is in memory; [fl, op) is in the ring only
+  uint32_t vlo = 0;  // the ring holds output positions [max(vlo, op - kStg), op)
+  int32_t wb = 0;
+  uint32_t wlim = 0;
+  bool have_win = false;
+  int32_t st = LZ4MI_OK;
+  PH_DECL
+
+  for (;;) {
+    bool general = true;
+    PH(7);
+    if (in_end - ip >= 8u) {
+      // ---- window: keep it while a whole sequence still fits behind ip, or it holds the block's end
+      bool fresh = false;
+      if (!have_win || !((ip - (uint32_t)wb) + kSeqIn <= kCw || (uint32_t)(wb + (int32_t)kCw) >= in_end)) {
+        cw_load(cw, src, in_end, ip, lane, wb, wlim);
+        have_win = true;
+        fresh = true;
+        PH_CNT(13);
+      }
+      // ---- chain of token starts: lane p of a 64-byte chunk parses byte cb + p
+      uint32_t cb = ip - (uint32_t)wb, r = 0, count = 0, tot = 0;
+      uint32_t tp = 0;  // lane j: window offset of token j
+      SeqFields f = spec_parse(cw, cb + lane, wlim);
+      uint32_t nx = f.nx - cb, sz = f.ll + f.ml;
+      uint64_t okm = ballot(f.ok), cxm = ballot(f.cplx);
+      for (;;) {
+        if (!((okm >> r) & 1ull)) {
+          // an extension run of three bytes or more, the end of the block, or the end of the window
+          general = ((cxm >> r) & 1ull) || (uint32_t)(wb + (int32_t)kCw) >= in_end || (fresh && count == 0);
+          if (!general) have_win = false;
+          break;
+        }
+        const uint32_t s = rdlane(sz, r);
+        if (tot + s > kBatchOut) { general = false; break; }
+        tp = lane == count ? cb + r : tp;
+        count++;
+        tot += s;
+        r = rdlane(nx, r);
+        if (count == kWave) { general = false; break; }
+        if (r >= kWave) {
+          cb += r;
+          r = 0;
+          f = spec_parse(cw, cb + lane, wlim);
+          nx = f.nx - cb;
+          sz = f.ll + f.ml;
+          okm = ballot(f.ok);
+          cxm = ballot(f.cplx);
+        }
+      }
+      uint32_t ip_stop = (uint32_t)wb + cb + r;
+      PH(0);
+
+      if (count) {
+        // ---- lane j owns sequence j
+        f = spec_parse(cw, tp, wlim);
+        const bool mine = lane < count;
+        const uint32_t ll = mine ? f.ll : 0u, ml = mine ? f.ml : 0u, dist = f.dist;
+        const uint32_t incl = wave_incl_scan(ll + ml);
+        const uint32_t o_lit = op + incl - (ll + ml);  // where the literals go
+        const uint32_t o_mat = o_lit + ll;             // where the match goes
+        // lz4_block_decoder.dart:33-35,61-63 and byte_writer.dart:97-104: a sequence that would fail
+        // any of them is left to the general loop, which names the failure
+        const bool good = incl <= cap - op && dist != 0u && (uint64_t)dist <= (uint64_t)o_mat + back_limit;
+        const uint64_t badm = ballot(mine && !good);
+        uint32_t nb = badm ? (uint32_t)__builtin_ctzll(badm) : count;
+        uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
+        const int32_t sp = (int32_t)o_mat - (int32_t)dist;  // match source (may lie in front of the block)
+        const int32_t lo = (int32_t)vlo > (int32_t)b1 - (int32_t)kStg ? (int32_t)vlo : (int32_t)b1 - (int32_t)kStg;
+        bool far = lane < nb && sp < lo;
+        {
+          // an out-of-ring source that the fetch below cannot serve: longer than it fetches, or
+          // (right after the general loop emptied the ring) reaching into output that is not in
+          // memory yet
+          const uint64_t fbm = ballot(far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl));
+          if (fbm) {
+            nb = (uint32_t)__builtin_ctzll(fbm);
+            b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
+            far = far && lane < nb;
+          }
+        }
+        if (nb < count) {
+          general = true;
+          have_win = true;
+          ip_stop = (uint32_t)wb + rdlane(tp, nb);
+        }
+        PH(1);
+        if (nb) {
+#ifdef LZ4MI_PROFILE
+          ph_c_[8 * 64] += 1; ph_c_[9 * 64] += nb; ph_c_[10 * 64] += (uint32_t)__builtin_popcountll(ballot(far));
+#endif
+          // ---- matches whose source is older than the ring: fetched from memory, four per round trip
+          for (uint64_t fm = ballot(far); fm;) {
+            int32_t fs[4];
+            uint32_t fd[4], fn[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+              fs[u] = 0; fd[u] = 0; fn[u] = 0;
+              if (fm) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(fm);
+                fm &= fm - 1ull;
+                fs[u] = (int32_t)rdlane((uint32_t)sp, j);
+                fd[u] = rdlane(o_mat, j);
+                fn[u] = rdlane(ml, j);
+              }
+            }
+            uint32_t v[4][kFarMax / kWave];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+              for (uint32_t t = 0; t < kFarMax / kWave; t++) {
+                v[u][t] = 0;
+                if (t * kWave < fn[u]) {
+                  const uint32_t idx = t * kWave + lane;
+                  if (idx < fn[u]) {
+                    const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
+                    v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+                  }
+                }
+              }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+              for (uint32_t t = 0; t < kFarMax / kWave; t++) {
+                if (t * kWave < fn[u]) {
+                  const uint32_t idx = t * kWave + lane;
+                  if (idx < fn[u]) stg[(fd[u] + goff + idx) & kStgMask] = (uint8_t)v[u][t];
+                }
+              }
+            }
+            vm_quiesce();
+          }
+
+          PH(2);
+          // ---- literals: lane j copies the first 32 bytes of its run, window -> ring
+          {
+            const uint32_t n = lane < nb ? ll : 0u;
+            const uint32_t d0 = o_lit + goff;
+            const uint32_t ndw = (n < 32u ? n : 32u) >> 2;
+            uint32_t wv[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) wv[k] = cw32(cw, f.ls + 4u * k);
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++)
+              if (k < ndw) ((lds_dp32 *)(stg + ((d0 + 4u * k) & kStgMask)))->v = wv[k];
+            {
+              // a dword written across the end of the ring left its tail in the pad: bring it round
+              const uint32_t c = kStg - (d0 & kStgMask);  // bytes from the run's start to the end of the ring
+              if ((c & 3u) != 0u && (c >> 2) < ndw) {
+                const uint32_t spill = 4u - (c & 3u);
+                for (uint32_t i = 0; i < spill; i++) stg[i] = stg[kStg + i];
+              }
+            }
+            if (n < 32u) {  // up to three bytes behind the last whole dword
+              const uint32_t tb = n & 3u, o = 4u * ndw;
+              uint32_t bv[3];
+#pragma unroll
+              for (uint32_t i = 0; i < 3; i++) bv[i] = cw8(cw, f.ls + o + i);
+#pragma unroll
+              for (uint32_t i = 0; i < 3; i++)
+                if (i < tb) stg[(d0 + o + i) & kStgMask] = (uint8_t)bv[i];
+            }
+            // what is left of runs longer than 32 bytes: one run after the other, 64 bytes per step
+            for (uint64_t lm = ballot(n > 32u); lm; lm &= lm - 1ull) {
+              const uint32_t j = (uint32_t)__builtin_ctzll(lm);
+              const uint32_t s0 = rdlane(f.ls, j) + 32u, dd = rdlane(d0, j) + 32u, len = rdlane(n, j) - 32u;
+              for (uint32_t k0 = 0; k0 < len; k0 += kWave) {
+                const uint32_t k = k0 + lane;
+                const uint32_t b = cw8(cw, s0 + k);
+                if (k < len) stg[(dd + k) & kStgMask] = (uint8_t)b;
+              }
+            }
+          }
+
+          PH(3);
+          // ---- matches in order, ring -> ring.  LDS operations of a wavefront execute in issue order, so a
+          // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
+          // byte by byte: output byte k is byte k mod dist of the period in front of the match.
+          const uint64_t nearm = ballot(lane < nb && !far);
+          for (uint64_t mm = nearm; mm; mm &= mm - 1ull) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
+            const uint32_t md = rdlane(o_mat, j) + goff, d = rdlane(dist, j), m = rdlane(ml, j);
+            const uint32_t ms = md - d;
+            uint32_t rr = lane, step = kWave;
+            if (d < m) {  // overlapping: replicate the period
+              if (d < kWave) {
+                rr = lane_mod(lane, d);
+                step = rdlane(rr, kWave - 1u) + 1u;  // 64 mod d
+                if (step == d) step = 0;
+              }
+            } else {
+              // plain copy: never wraps, so the same arithmetic with a period that is never reached
+            }
+            const uint32_t per = d < m ? d : 0x7fffffffu;
+            for (uint32_t k0 = 0; k0 < m; k0 += 4 * kWave) {
+              uint32_t bv[4], ro[4];
+#pragma unroll
+              for (uint32_t u = 0; u < 4; u++) {
+                ro[u] = rr;
+                rr += step;
+                if (rr >= per) rr -= per;
+              }
+#pragma unroll
+              for (uint32_t u = 0; u < 4; u++) {
+                bv[u] = 0;
+                if (k0 + u * kWave < m) bv[u] = stg[(ms + ro[u]) & kStgMask];
+              }
+#pragma unroll
+              for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t k = k0 + u * kWave + lane;
+                if (k0 + u * kWave < m && k < m) stg[(md + k) & kStgMask] = (uint8_t)bv[u];
+              }
+            }
+          }
+
+          PH(4);
+          // ---- the batch goes to memory in aligned 16-byte pieces
+          fl = stg_flush(stg, out, goff, fl, b1, false, lane);
+          op = b1;
+          PH(5);
+        }
+      }
+      ip = ip_stop;
+    }
+    if (!general) continue;
+
+    // ---- one sequence through the general loop (and every end of a block)
+    PH(7);
+    PH_CNT(11);
+    fl = stg_flush(stg, out, goff, fl, op, true, lane);
     uint32_t di = 0, dn = 0;
-    st = groups ? decode_run<STRICT, HAS_PREFIX, true, 1>(src + ip, src_len - ip, dst, op_start + op, cap - op,
-                                                              back_limit + op, prefix, prefix_len, ring, lane, di, dn)
-                : decode_run<STRICT, HAS_PREFIX, false, kMsReenter>(src + ip, src_len - ip, dst, op_start + op, cap - op,
-                                                               back_limit + op, prefix, prefix_len, ring, lane, di,
-                                                               dn);
+    st = decode_run<STRICT, HAS_PREFIX, true>(src + ip, in_end - ip, dst, op_start + op, cap - op, back_limit + op,
+                                              prefix, prefix_len, stg, lane, di, dn);
     ip += di;
     op += dn;
+    fl = op;
+    vlo = op;  // the general loop used the ring for itself
+    PH(6);
     if (st != kSwitchRun) break;
   }
+  PH_FLUSH(g_dec_phase, lane);
   out_len = op;
   return st;
 }
 
-// A launch is two kernels on the stream.  decode_kernel takes every block through the plain
-// loop; a block that turns out to consist of short sequences is put down at the sequence boundary
-// it has reached (block index, bytes consumed, bytes produced go into the redo list) and the
-// wavefront moves on.  decode_redo_kernel then finishes the listed blocks with the group variant.
-// Long-match data never pays for the group code (it is not in the first kernel at all); when the
-// list stays empty the second kernel returns at once.
-struct RedoEntry { uint32_t block, in_used, out_len, pad; };
-
-// In the second kernel the launch arguments are not held in registers across a block: its loops
-// keep their control state in scalar registers and need nearly all of them (holding the
-// arguments too made the compiler spill scalars in the sequence loop).  They are read again
-// from the kernel argument segment (BatchArgs first, then the other arguments in order).
-struct DecodeKArgs {
-  BatchArgs a;
-  uint32_t *counter;
-  uint32_t *redo_count;
-  RedoEntry *redo;
-  const uint32_t *order;
-};
-typedef const volatile __attribute__((address_space(4))) DecodeKArgs *DecodeKArgsPtr;
-
-struct BlockIo {
-  const uint8_t *src;
-  uint32_t src_len;
-  uint8_t *dst;
-  uint32_t cap;
-};
-__device__ __forceinline__ BlockIo block_io(DecodeKArgsPtr ka, uint32_t b) {
-  BlockIo io;
-  const uint64_t *src_off = ka->a.src_off, *dst_off = ka->a.dst_off;
-  const uint32_t *src_len_v = ka->a.src_len, *dst_cap = ka->a.dst_cap;
-  io.src = ka->a.src + uni64(src_off ? src_off[b] : (uint64_t)b * ka->a.src_stride);
-  if (src_len_v) {
-    io.src_len = uni(src_len_v[b]);
-  } else {
-    const uint32_t u = ka->a.src_len_uniform;
-    const uint64_t start = (uint64_t)b * u, tot = ka->a.src_total;
-    const uint64_t left = tot > start ? tot - start : 0;
-    io.src_len = left < u ? (uint32_t)left : u;
-  }
-  io.dst = ka->a.dst + uni64(dst_off ? dst_off[b] : (uint64_t)b * ka->a.dst_stride);
-  io.cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
-  return io;
-}
-
+// One wavefront per workgroup: a wavefront's LDS (ring + window) is then the unit the hardware
+// packs into a CU's 160 KiB.
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *counter, uint32_t *redo_count,
-                                                     RedoEntry *redo, const uint32_t *order) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
+__global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStg + kStgPad];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   const uint32_t lane = lane_id();
-  lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
+  lds_u8 *stg = (lds_u8 *)s_stg;
+  lds_u8 *cw = (lds_u8 *)s_cw;
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
   const uint32_t prefix_len = a.dict_len;
-  // When the launch has a wavefront for every block, a wavefront's block is its own index (thousands
-  // of wavefronts starting at once would otherwise serialise on the queue head); larger batches
-  // are handed out through the queue.
-  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
+  // When the launch has a wavefront for every block, a wavefront's block is its own index; larger
+  // batches are handed out through the queue, where a wavefront's first block is still its own
+  // index (thousands of wavefronts popping one queue head at launch serialise on it).
+  const uint32_t nwaves = gridDim.x;
   const bool direct = a.nblocks <= nwaves;
-  // a wavefront's first block is its own index (thousands of wavefronts popping one queue head at
-  // launch serialise on it); the queue hands out the blocks behind those
-  uint32_t b = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  uint32_t b = uni(blockIdx.x);
   for (;; b = direct ? 0xffffffffu : nwaves + next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
@@ -567,53 +755,18 @@ __global__ __launch_bounds__(256) void decode_kernel(BatchArgs a, uint32_t *coun
     const uint32_t src_len = uni(block_src_len(a, b));
     uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
-    uint32_t used = 0, out_len = 0;
-    __builtin_amdgcn_s_setprio(0);
+    uint32_t out_len = 0;
 #ifdef LZ4MI_PROFILE
     if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int32_t st = decode_run<STRICT, HAS_PREFIX, false, kMsEnter>(src, src_len, dst, 0, cap, prefix_len, prefix,
-                                                                   prefix_len, ring, lane, used, out_len);
+    const int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg,
+                                                        cw, lane, out_len);
 #ifdef LZ4MI_PROFILE
     if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (lane == 0) {
-      if (st == kSwitchRun) {
-        const uint32_t k = atomicAdd(redo_count, 1u);
-        RedoEntry e = {b, used, out_len, 0u};
-        redo[k] = e;
-      } else {
-        a.out_len[b] = out_len;
-        a.status[b] = st;
-      }
-    }
-  }
-}
-
-template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(256) void decode_redo_kernel(BatchArgs, uint32_t *, uint32_t *, RedoEntry *, const uint32_t *) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][kRing];
-  const uint32_t lane = lane_id();
-  lds_u8 *ring = (lds_u8 *)s_ring[uni(threadIdx.x / kWave)];
-  DecodeKArgsPtr ka = (DecodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-  const uint32_t nredo = *ka->redo_count;
-  if (nredo == 0) return;
-  const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
-  const bool direct = nredo <= nwaves;
-  uint32_t k = direct ? uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave)
-                      : next_block(ka->counter + 1, lane);  // the second kernel's own queue head
-  for (;; k = direct ? 0xffffffffu : next_block(ka->counter + 1, lane)) {
-    if (k >= nredo) break;
-    const uint32_t b = uni(ka->redo[k].block), ip = uni(ka->redo[k].in_used), op = uni(ka->redo[k].out_len);
-    const BlockIo io = block_io(ka, b);
-    const uint8_t *prefix = ka->a.dict;
-    const uint32_t prefix_len = ka->a.dict_len;
-    uint32_t more = 0;
-    const int32_t st = decode_block<STRICT, HAS_PREFIX, true>(io.src + ip, io.src_len - ip, io.dst, op, io.cap - op,
-                                                              prefix_len + op, prefix, prefix_len, ring, lane, more);
-    if (lane == 0) {
-      ka->a.out_len[b] = op + more;
-      ka->a.status[b] = st;
+      a.out_len[b] = out_len;
+      a.status[b] = st;
     }
   }
 }
@@ -623,8 +776,10 @@ __global__ __launch_bounds__(256) void decode_redo_kernel(BatchArgs, uint32_t *,
 // (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
 // serial, so one wavefront walks the blocks in order over one contiguous output.
 __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[kRing];
-  lds_u8 *ring = (lds_u8 *)s_ring;
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStg + kStgPad];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
+  lds_u8 *stg = (lds_u8 *)s_stg;
+  lds_u8 *cw = (lds_u8 *)s_cw;
   const uint32_t lane = lane_id();
   uint64_t start = 0;
   uint32_t b = 0;
@@ -639,7 +794,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, ring, lane,
+      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, lane,
                                      produced);
     }
     if (lane == 0) {
@@ -699,31 +854,33 @@ __global__ __launch_bounds__(256) void decode_order_kernel(BatchArgs a, uint32_t
   else if (valid) order[a.nblocks - 1u - (bl + (uint32_t)__builtin_popcountll(lm & below))] = b;
 }
 
-void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *redo_count, void *redo,
-                   uint32_t *order_cnt, uint32_t *order, uint32_t grid, hipStream_t s) {
-  if (order && a.nblocks > grid * 4u)  // only a queued launch has an order to choose
+// Resident wavefronts (= workgroups) per CU of a decode kernel: bounded by its LDS and registers.
+template <typename K>
+static uint32_t resident_per_cu(K kernel) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64, 0) != hipSuccess || n < 1) n = 8;
+  return (uint32_t)n;
+}
+
+void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
+                   uint32_t cu_count, hipStream_t s) {
+  // one wavefront per workgroup; as many as stay resident (one that is not would hold its first block back)
+  static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>), resident_per_cu(decode_kernel<false, true>),
+                                     resident_per_cu(decode_kernel<true, false>), resident_per_cu(decode_kernel<true, true>)};
+  const bool pre = a.dict_len != 0;
+  const uint32_t slots = cu_count * per_cu[(strict ? 2 : 0) + (pre ? 1 : 0)];
+  const uint32_t grid = a.nblocks < slots ? a.nblocks : slots;
+  if (order && a.nblocks > grid)  // only a queued launch has an order to choose
     hipLaunchKernelGGL(decode_order_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, s, a, order_cnt, order);
   else
     order = nullptr;
-  dim3 g(grid), blk(256);
-  RedoEntry *r = (RedoEntry *)redo;
-  const bool pre = a.dict_len != 0;
+  dim3 g(grid), blk(64);
   if (strict) {
-    if (pre) {
-      hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r, order);
-      hipLaunchKernelGGL((decode_redo_kernel<true, true>), g, blk, 0, s, a, counter, redo_count, r, order);
-    } else {
-      hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r, order);
-      hipLaunchKernelGGL((decode_redo_kernel<true, false>), g, blk, 0, s, a, counter, redo_count, r, order);
-    }
+    if (pre) hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, order);
+    else hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, order);
   } else {
-    if (pre) {
-      hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r, order);
-      hipLaunchKernelGGL((decode_redo_kernel<false, true>), g, blk, 0, s, a, counter, redo_count, r, order);
-    } else {
-      hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r, order);
-      hipLaunchKernelGGL((decode_redo_kernel<false, false>), g, blk, 0, s, a, counter, redo_count, r, order);
-    }
+    if (pre) hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, order);
+    else hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, order);
   }
 }
 

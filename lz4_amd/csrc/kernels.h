@@ -67,11 +67,10 @@ struct ChainArgs {
 };
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s);
-// counter: two consecutive words (queue heads of the two kernels) and redo_count, all zero at launch;
-// redo: 16 bytes per block of the batch; order: one word per block (or null: index order), order_cnt:
-// two words, zero at launch.
-void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *redo_count, void *redo,
-                   uint32_t *order_cnt, uint32_t *order, uint32_t grid, hipStream_t s);
+// counter: the queue head, zero at launch; order: one word per block (or null: index order),
+// order_cnt: two words, zero at launch.  The grid is sized to the wavefronts that stay resident.
+void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
+                   uint32_t cu_count, hipStream_t s);
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
                         uint32_t grid, hipStream_t s);
 void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_table, hipStream_t s);

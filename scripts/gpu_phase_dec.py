@@ -8,8 +8,9 @@ from tools.corpus import corpus_block
 codec = DeviceCodec(0)
 L = N.load()
 NB = int(__import__('os').environ.get('NB', '1024'))
-names = ['0 parse', '1 short literal', '2 long literal', '3 short match ring', '4 short match global', '5 long match',
-         '6 offset+length parse', '7', '8 #short lit', '9 #long lit', '10 #ring match', '11 #global match', '12 realtime ticks (100 MHz)', '13 #long match', '14', '15 total cycles']
+names = ['0 window + token chain', '1 lane fields, scan, checks', '2 out-of-ring matches', '3 literals', '4 matches', '5 flush',
+         '6 general loop', '7 other', '8 #batches', '9 #batched sequences', '10 #out-of-ring matches', '11 #general steps',
+         '12 realtime ticks (100 MHz)', '13 #window loads', '14', '15 total cycles']
 for arg in sys.argv[1:] or ['5']:
     idx = [int(x) for x in arg.split(',')]
     blocks = [corpus_block(i) for i in idx]
