@@ -338,78 +338,90 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 
 // ---------------------------------------------------------------------------------------------
 // Batch loop.
-#ifndef LZ4MI_STG
-#define LZ4MI_STG 8192
+#ifndef LZ4MI_HIST
+#define LZ4MI_HIST 4096
 #endif
-constexpr uint32_t kStg = LZ4MI_STG;       // LDS ring of recent output per wavefront (>= kRing: the general loop borrows it)
-constexpr uint32_t kStgMask = kStg - 1;
-constexpr uint32_t kStgPad = 16;           // behind the ring: catches the tail of a dword written across the wrap
-constexpr uint32_t kBatchOut = kStg / 2;   // most output bytes of one batch; the other half is history
-constexpr uint32_t kCw = 2048;             // compressed window in LDS
+#ifndef LZ4MI_BATCH
+#define LZ4MI_BATCH 4096
+#endif
+constexpr uint32_t kH = LZ4MI_HIST;         // output bytes kept in LDS in front of a batch (multiple of 1024)
+constexpr uint32_t kBatchOut = LZ4MI_BATCH; // most output bytes of one batch
+constexpr uint32_t kStgBytes = kH + 16 + kBatchOut + 16;  // staging buffer: history, alignment slack, batch, store slack
+constexpr uint32_t kCw = 2048;              // compressed window in LDS
 constexpr uint32_t kCwPad = 16;
-constexpr uint32_t kCwTop = kCw + kCwPad - 4;  // highest offset a 4-byte read may start at
-constexpr uint32_t kLenMax = 15 + 255 + 254;   // longest literal run (match: + 4) with two extension bytes
-constexpr uint32_t kSeqIn = 1 + 2 + kLenMax + 2 + 2 + 4;  // compressed bytes one batched sequence may span, plus slack
-constexpr uint32_t kFarMax = 320;          // longest match the out-of-ring path fetches (5 steps of 64 bytes)
-static_assert(kStg >= kRing, "the general loop uses the first kRing bytes of the staging ring");
+constexpr uint32_t kCwTop = kCw + kCwPad - 8;   // highest offset an 8-byte read may start at
+constexpr uint32_t kLitMax = 15 + 6 * 255 + 254;  // longest literal run of a batched sequence (up to seven extension bytes)
+constexpr uint32_t kMatMax = 19 + 5 * 255 + 254;  // longest match (up to six extension bytes)
+constexpr uint32_t kSeqIn = 8 + kLitMax + 8 + 8;  // compressed bytes a batched sequence may span, plus slack
+constexpr uint32_t kSeqTyp = 320;           // a window with fewer bytes than this behind ip is not worth a parse
+constexpr uint32_t kFarMax = 320;           // bytes per match the out-of-buffer path fetches (5 steps of 64)
+constexpr uint32_t kDesc = 65;              // sequence descriptors (8 bytes each): one per lane and a spare
+static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at least one sequence");
+static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
+static_assert(kH % 1024 == 0, "layout");
 
 struct __attribute__((packed)) DP32 { uint32_t v; };
+struct __attribute__((packed)) DP64 { uint64_t v; };
 typedef __attribute__((address_space(3))) DP32 lds_dp32;
+typedef __attribute__((address_space(3))) DP64 lds_dp64;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) u32x2 lds_u64v;
 
-// four bytes at window offset a (clamped: a read past the window returns bytes that no caller uses)
+// bytes at window offset a (clamped: a read past the window returns bytes that no caller uses)
 __device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
   a = a < kCwTop ? a : kCwTop;
   return ((const lds_dp32 *)(cw + a))->v;
 }
-__device__ __forceinline__ uint32_t cw8(const lds_u8 *cw, uint32_t a) {
-  a = a < kCwTop + 3 ? a : kCwTop + 3;
-  return cw[a];
+__device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
+  a = a < kCwTop ? a : kCwTop;
+  return ((const lds_dp64 *)(cw + a))->v;
 }
 
-// Parses the byte at window offset a as a token.  ok: the sequence has at most two extension bytes per
-// length and its header lies inside the first wlim bytes of the window (with up to two bytes of
-// slack), so every field read here is real.  cplx: a third extension byte would be needed.
+// Parses the byte at window offset a as a token.  The literal length is read with up to seven
+// extension bytes; the match length is taken with ONE extension byte (nx1 = where the next token
+// starts under that assumption), which is all the chain of token starts needs in the common case.
+// A match whose first extension byte is 255 (`mlong`) is finished by seq_match_long.
 struct SeqFields {
-  uint32_t ll, ls, ml, dist, nx;  // literal length, window offset of the literals, match length, offset, next token
-  bool ok, cplx;
+  uint32_t ll, ls, q, ml, dist, nx1;  // literal length, window offsets of literals and offset field, match length, distance
+  bool ok, mlong;
 };
+__device__ __forceinline__ uint32_t ff_bytes(uint64_t x) {  // bytes of 0xFF at the low end of x (x has a byte that is not)
+  return (uint32_t)__builtin_ctzll(~x) >> 3;
+}
 __device__ __forceinline__ SeqFields spec_parse(const lds_u8 *cw, uint32_t a, uint32_t wlim) {
   SeqFields f;
-  const uint32_t t4 = cw32(cw, a);
-  const uint32_t tok = t4 & 255u, e1 = (t4 >> 8) & 255u, e2 = (t4 >> 16) & 255u;
-  uint32_t ll = tok >> 4, xl = 0;
-  bool cplx = false;
-  if (ll == 15u) {
-    ll += e1;
-    xl = 1;
-    if (e1 == 255u) {
-      ll += e2;
-      xl = 2;
-      cplx = e2 == 255u;
-    }
-  }
-  f.ll = ll;
-  f.ls = a + 1u + xl;
-  const uint32_t q = f.ls + ll;
-  const uint32_t o4 = cw32(cw, q);
+  const uint64_t t8 = cw64(cw, a);
+  const uint32_t tok = (uint32_t)t8 & 255u;
+  const uint32_t ll0 = tok >> 4, mc = tok & 15u;
+  const bool isl = ll0 == 15u, ism = mc == 15u;
+  const uint64_t ext = t8 >> 8;                            // seven extension bytes, then a zero byte
+  const uint32_t nff = ff_bytes(ext);                      // 0..7 bytes of 255 in front of the closing byte
+  const uint32_t eb = (uint32_t)(ext >> (8u * (nff & 7u))) & 255u;
+  f.ll = isl ? 15u + 255u * nff + eb : ll0;
+  f.ls = a + 1u + (isl ? nff + 1u : 0u);
+  f.q = f.ls + f.ll;
+  const uint32_t o4 = cw32(cw, f.q);
+  const uint32_t f1 = (o4 >> 16) & 255u;
   f.dist = o4 & 0xffffu;
-  const uint32_t f1 = (o4 >> 16) & 255u, f2 = o4 >> 24;
-  const uint32_t mc = tok & 15u;
-  uint32_t ml = mc + 4u, xm = 0;
-  if (mc == 15u) {
-    ml += f1;
-    xm = 1;
-    if (f1 == 255u) {
-      ml += f2;
-      xm = 2;
-      cplx = cplx || f2 == 255u;
-    }
-  }
-  f.ml = ml;
-  f.nx = q + 2u + xm;
-  f.cplx = cplx;
-  f.ok = !cplx && q + 4u <= wlim;
+  f.ml = mc + 4u + (ism ? f1 : 0u);
+  f.nx1 = f.q + 2u + (ism ? 1u : 0u);
+  f.mlong = ism && f1 == 255u;
+  // the closing byte of the literal length is one of the seven read, and the header as far as it was
+  // read lies inside the window
+  f.ok = !(isl && nff == 7u) && f.nx1 <= wlim;
   return f;
+}
+// Match length and next-token offset of a sequence whose match length has two or more extension bytes
+// (q = window offset of its offset field).  ok: at most six extension bytes, all inside the window.
+__device__ __forceinline__ void seq_match_long(const lds_u8 *cw, uint32_t q, uint32_t wlim, uint32_t &ml, uint32_t &nx,
+                                               bool &ok) {
+  const uint64_t o8 = cw64(cw, q);
+  const uint64_t ext = o8 >> 16;                            // six extension bytes, then zero bytes
+  const uint32_t nff = ff_bytes(ext);                       // >= 1 here
+  const uint32_t eb = (uint32_t)(ext >> (8u * (nff & 7u))) & 255u;
+  ml = 19u + 255u * nff + eb;
+  nx = q + 2u + nff + 1u;
+  ok = nff < 6u && nx <= wlim;
 }
 
 // Loads kCw bytes of the block, starting at the 16-byte aligned address at or below src + ip, into the
@@ -421,36 +433,32 @@ __device__ __forceinline__ void cw_load(lds_u8 *cw, const uint8_t *__restrict__ 
   const uint8_t *g = src + wb;
   const uint32_t avail = in_end - (uint32_t)wb;
   wlim = avail < kCw ? avail : kCw;
-  u32x4 v[kCw / 1024];
-#pragma unroll
-  for (uint32_t k = 0; k < kCw / 1024; k++) {
-    const uint32_t o = 1024u * k + 16u * lane;
-    v[k] = u32x4{0, 0, 0, 0};
-    if (o < wlim) v[k] = *(const u32x4 *)(g + o);  // an aligned 16 bytes that hold at least one byte of the block
-  }
-#pragma unroll
-  for (uint32_t k = 0; k < kCw / 1024; k++) *(lds_u128 *)(cw + 1024u * k + 16u * lane) = v[k];
+  // every lane loads (a lane past the end re-reads the window's first 16 bytes): no branch around the loads
+  const uint32_t o0 = 16u * lane, o1 = 1024u + 16u * lane;
+  const u32x4 v0 = *(const u32x4 *)(g + (o0 < wlim ? o0 : 0u));
+  const u32x4 v1 = *(const u32x4 *)(g + (o1 < wlim ? o1 : 0u));
+  *(lds_u128 *)(cw + o0) = v0;
+  *(lds_u128 *)(cw + o1) = v1;
   vm_quiesce();
 }
 
-// lane mod d for d in 1..63 (exact: (lane + 0.5) / d is at least 1/128 away from every integer)
-__device__ __forceinline__ uint32_t lane_mod(uint32_t lane, uint32_t d) {
-  const float q = ((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)d);
-  return lane - (uint32_t)q * d;
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Writes output positions [from, to) of the ring to memory.  Positions are block-relative; the ring
-// index of position p is (p + goff) & kStgMask with goff = low four address bits of position 0, so a
-// 16-byte aligned piece of memory is a 16-byte aligned piece of the ring.  With `all` the range is
-// written to the last byte, otherwise up to the last 16-byte boundary (the rest follows with the
-// next batch).  Returns the new flushed-up-to position.
-__device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, uint32_t goff, uint32_t from, uint32_t to,
+// Staging buffer: a linear image of output positions [sbase, sbase + kStgBytes): position p sits at offset
+// p - sbase, and sbase + (low four address bits of position 0) is a multiple of 16, so a 16-byte aligned
+// piece of memory is a 16-byte aligned piece of the buffer.
+//
+// Writes positions [from, to) of the buffer to memory; with `all` to the last byte, otherwise up to the
+// last 16-byte boundary (the rest follows with the next batch).  Returns the new flushed-up-to position.
+__device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, uint32_t sneg, uint32_t from, uint32_t to,
                                               bool all, uint32_t lane) {
   if (from >= to) return from;
-  const uint32_t head = (16u - ((from + goff) & 15u)) & 15u;
+  const uint32_t head = (0u - (from + sneg)) & 15u;
   if (head) {
     const uint32_t n = head < to - from ? head : to - from;
-    if (lane < n) out[from + lane] = stg[(from + goff + lane) & kStgMask];
+    if (lane < n) out[from + lane] = stg[from + sneg + lane];
     from += n;
   }
   const uint32_t pieces = (to - from) >> 4;
@@ -459,7 +467,7 @@ __device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, u
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++) {
       const uint32_t c = c0 + u * kWave + lane;
-      v[u] = *(const lds_u128 *)(stg + ((from + goff + 16u * (c < pieces ? c : 0u)) & kStgMask));
+      v[u] = *(const lds_u128 *)(stg + from + sneg + 16u * (c < pieces ? c : 0u));
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++) {
@@ -469,7 +477,7 @@ __device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, u
   }
   from += 16u * pieces;
   if (all && from < to) {
-    if (lane < to - from) out[from + lane] = stg[(from + goff + lane) & kStgMask];
+    if (lane < to - from) out[from + lane] = stg[from + sneg + lane];
     from = to;
   }
   return from;
@@ -479,13 +487,14 @@ template <bool STRICT, bool HAS_PREFIX>
 __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                 const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                 const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                                lds_u8 *stg, lds_u8 *cw, uint32_t lane, uint32_t &out_len) {
+                                                lds_u8 *stg, lds_u8 *cw, lds_u64v *desc, uint32_t lane, uint32_t &out_len) {
   const uint32_t in_end = src_len;
   uint8_t *const out = dst + op_start;
   const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
   uint32_t ip = 0, op = 0;
-  uint32_t fl = 0;   // output in front of this position is in memory; [fl, op) is in the ring only
-  uint32_t vlo = 0;  // the ring holds output positions [max(vlo, op - kStg), op)
+  uint32_t fl = 0;          // output in front of this position is in memory; [fl, op) is in the buffer only
+  int32_t vlo = 0;          // the buffer holds output positions [max(vlo, sbase), op)
+  uint32_t sneg = kH + goff;  // buffer offset of position p is p + sneg (sneg = -sbase)
   int32_t wb = 0;
   uint32_t wlim = 0;
   bool have_win = false;
@@ -496,86 +505,133 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     bool general = true;
     PH(7);
     if (in_end - ip >= 8u) {
-      // ---- window: keep it while a whole sequence still fits behind ip, or it holds the block's end
-      bool fresh = false;
-      if (!have_win || !((ip - (uint32_t)wb) + kSeqIn <= kCw || (uint32_t)(wb + (int32_t)kCw) >= in_end)) {
+      // ---- window: keep it while a typical sequence still fits behind ip, or it holds the block's end
+      if (!have_win || !((ip - (uint32_t)wb) + kSeqTyp <= kCw || (uint32_t)(wb + (int32_t)kCw) >= in_end)) {
         cw_load(cw, src, in_end, ip, lane, wb, wlim);
         have_win = true;
-        fresh = true;
         PH_CNT(13);
       }
-      // ---- chain of token starts: lane p of a 64-byte chunk parses byte cb + p
-      uint32_t cb = ip - (uint32_t)wb, r = 0, count = 0, tot = 0;
-      uint32_t tp = 0;  // lane j: window offset of token j
-      SeqFields f = spec_parse(cw, cb + lane, wlim);
-      uint32_t nx = f.nx - cb, sz = f.ll + f.ml;
-      uint64_t okm = ballot(f.ok), cxm = ballot(f.cplx);
-      for (;;) {
-        if (!((okm >> r) & 1ull)) {
-          // an extension run of three bytes or more, the end of the block, or the end of the window
-          general = ((cxm >> r) & 1ull) || (uint32_t)(wb + (int32_t)kCw) >= in_end || (fresh && count == 0);
-          if (!general) have_win = false;
-          break;
-        }
-        const uint32_t s = rdlane(sz, r);
-        if (tot + s > kBatchOut) { general = false; break; }
-        tp = lane == count ? cb + r : tp;
-        count++;
-        tot += s;
-        r = rdlane(nx, r);
-        if (count == kWave) { general = false; break; }
-        if (r >= kWave) {
-          cb += r;
-          r = 0;
-          f = spec_parse(cw, cb + lane, wlim);
-          nx = f.nx - cb;
-          sz = f.ll + f.ml;
-          okm = ballot(f.ok);
-          cxm = ballot(f.cplx);
+      // ---- slide the buffer so that the batch starts right behind kH bytes of history
+      {
+        const uint32_t shift = (op + sneg - kH) & ~15u;  // op + sneg >= kH always
+        if (shift) {
+          u32x4 v[kH / 1024 + 1];
+#pragma unroll
+          for (uint32_t u = 0; u <= kH / 1024; u++) {
+            const uint32_t c = u * kWave + (u < kH / 1024 ? lane : 0u);
+            v[u] = *(const lds_u128 *)(stg + shift + 16u * c);
+          }
+#pragma unroll
+          for (uint32_t u = 0; u <= kH / 1024; u++) {
+            const uint32_t c = u * kWave + (u < kH / 1024 ? lane : 0u);
+            *(lds_u128 *)(stg + 16u * c) = v[u];
+          }
+          sneg -= shift;
         }
       }
+      // ---- chain of token starts: lane p of a 64-byte chunk parses byte cb + p as a token; the real
+      // starts are followed with one cross-lane read each and noted in a bit mask; the lanes that stand
+      // on a start put their fields into the descriptor list
+      uint32_t cb = ip - (uint32_t)wb, r = 0, count = 0, tot = 0;
+      bool notok = false;
+      for (;;) {
+        const SeqFields f = spec_parse(cw, cb + lane, wlim);
+        const uint32_t nx = f.nx1 - cb;
+        const uint64_t okm = ballot(f.ok);
+        uint64_t starts = 0;
+        for (;;) {
+          if (!((okm >> r) & 1ull)) { notok = true; break; }
+          starts |= 1ull << r;
+          r = rdlane(nx, r);
+          if (r >= kWave) break;
+        }
+        uint32_t ml = f.ml;
+        const uint64_t lm = ballot(f.mlong) & starts;
+        if (lm) {
+          // the first start with a long match ends this chunk: its real length and successor are read now
+          const uint32_t h = (uint32_t)__builtin_ctzll(lm);
+          uint32_t mlx, nxx;
+          bool okx;
+          seq_match_long(cw, f.q, wlim, mlx, nxx, okx);
+          starts &= (2ull << h) - 1ull;
+          notok = false;
+          r = rdlane(nxx, h) - cb;
+          if (!((ballot(okx) >> h) & 1ull)) {  // not a batched sequence after all
+            starts &= (1ull << h) - 1ull;
+            notok = true;
+            r = h;
+          }
+          if (lane == h) ml = mlx;
+        }
+        const bool st_lane = (starts >> lane) & 1ull;
+        if (st_lane) {
+          u32x2 d;
+          d.x = f.ls | (f.ll << 16);
+          d.y = ml | (f.dist << 16);
+          desc[count + mbcnt64(starts)] = d;
+        }
+        count += (uint32_t)__builtin_popcountll(starts);
+        tot += rdlane(wave_incl_scan(st_lane ? f.ll + ml : 0u), kWave - 1u);
+        if (notok || count > kWave - 22u || tot > kBatchOut - 512u) break;
+        cb += r;
+        r = 0;
+      }
       uint32_t ip_stop = (uint32_t)wb + cb + r;
+      if (notok) {
+        // a length with too many extension bytes, the end of the block, or the end of the window.  A window
+        // that was loaded at this token holds any sequence the batch takes, so there it is not the window.
+        general = (uint32_t)(wb + (int32_t)kCw) >= in_end || cb + r < 16u;
+        if (!general) have_win = false;
+      } else {
+        general = false;
+      }
       PH(0);
 
       if (count) {
         // ---- lane j owns sequence j
-        f = spec_parse(cw, tp, wlim);
+        const u32x2 dd = desc[lane < count ? lane : 0u];
         const bool mine = lane < count;
-        const uint32_t ll = mine ? f.ll : 0u, ml = mine ? f.ml : 0u, dist = f.dist;
+        const uint32_t ls = dd.x & 0xffffu, ll = mine ? dd.x >> 16 : 0u;
+        const uint32_t ml = mine ? dd.y & 0xffffu : 0u, dist = dd.y >> 16;
         const uint32_t incl = wave_incl_scan(ll + ml);
         const uint32_t o_lit = op + incl - (ll + ml);  // where the literals go
         const uint32_t o_mat = o_lit + ll;             // where the match goes
         // lz4_block_decoder.dart:33-35,61-63 and byte_writer.dart:97-104: a sequence that would fail
         // any of them is left to the general loop, which names the failure
         const bool good = incl <= cap - op && dist != 0u && (uint64_t)dist <= (uint64_t)o_mat + back_limit;
-        const uint64_t badm = ballot(mine && !good);
-        uint32_t nb = badm ? (uint32_t)__builtin_ctzll(badm) : count;
-        uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
         const int32_t sp = (int32_t)o_mat - (int32_t)dist;  // match source (may lie in front of the block)
-        const int32_t lo = (int32_t)vlo > (int32_t)b1 - (int32_t)kStg ? (int32_t)vlo : (int32_t)b1 - (int32_t)kStg;
-        bool far = lane < nb && sp < lo;
-        {
-          // an out-of-ring source that the fetch below cannot serve: longer than it fetches, or
-          // (right after the general loop emptied the ring) reaching into output that is not in
-          // memory yet
-          const uint64_t fbm = ballot(far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl));
-          if (fbm) {
-            nb = (uint32_t)__builtin_ctzll(fbm);
-            b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
-            far = far && lane < nb;
-          }
-        }
-        if (nb < count) {
-          general = true;
+        const int32_t lo = vlo > -(int32_t)sneg ? vlo : -(int32_t)sneg;  // lowest position the buffer holds
+        bool far = mine && sp < lo;
+        // an out-of-buffer source that is longer than the fetch below takes, or that reaches into output
+        // not yet in memory (possible right after the general loop): general loop
+        const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
+        const uint64_t badm = ballot(bad), overm = ballot(mine && incl > kBatchOut);
+        const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
+        const uint32_t nover = overm ? (uint32_t)__builtin_ctzll(overm) : kWave;
+        uint32_t nb = count;
+        if (nbad < nb || nover < nb) {
+          nb = nbad < nover ? nbad : nover;
+          general = nbad <= nover;
           have_win = true;
-          ip_stop = (uint32_t)wb + rdlane(tp, nb);
+          const uint32_t lsn = rdlane(ls, nb), lln = rdlane(dd.x >> 16, nb);
+          ip_stop = (uint32_t)wb + lsn - 1u - (lln >= 15u ? (lln - 15u) / 255u + 1u : 0u);
+        }
+        const uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
+        far = far && lane < nb;
+        const bool near = lane < nb && !far;
+        {
+          u32x2 d;  // match descriptor: source and destination as buffer offsets, length (0: nothing to do), distance
+          d.x = ((uint32_t)sp + sneg) | ((o_mat + sneg) << 16);
+          d.y = (near ? ml : 0u) | (dist << 16);
+          desc[lane] = d;
+          if (lane == 0) desc[kWave] = u32x2{0u, 0u};
         }
         PH(1);
         if (nb) {
 #ifdef LZ4MI_PROFILE
           ph_c_[8 * 64] += 1; ph_c_[9 * 64] += nb; ph_c_[10 * 64] += (uint32_t)__builtin_popcountll(ballot(far));
 #endif
-          // ---- matches whose source is older than the ring: fetched from memory, four per round trip
+          // ---- matches whose source is older than the buffer: fetched from memory, four per round trip
           for (uint64_t fm = ballot(far); fm;) {
             int32_t fs[4];
             uint32_t fd[4], fn[4];
@@ -586,7 +642,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
                 const uint32_t j = (uint32_t)__builtin_ctzll(fm);
                 fm &= fm - 1ull;
                 fs[u] = (int32_t)rdlane((uint32_t)sp, j);
-                fd[u] = rdlane(o_mat, j);
+                fd[u] = rdlane(o_mat, j) + sneg;
                 fn[u] = rdlane(ml, j);
               }
             }
@@ -611,98 +667,95 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
               for (uint32_t t = 0; t < kFarMax / kWave; t++) {
                 if (t * kWave < fn[u]) {
                   const uint32_t idx = t * kWave + lane;
-                  if (idx < fn[u]) stg[(fd[u] + goff + idx) & kStgMask] = (uint8_t)v[u][t];
+                  if (idx < fn[u]) stg[fd[u] + idx] = (uint8_t)v[u][t];
                 }
               }
             }
             vm_quiesce();
           }
-
           PH(2);
-          // ---- literals: lane j copies the first 32 bytes of its run, window -> ring
+
+          // ---- literals: lane j copies its run, window -> buffer, eight bytes at a time
           {
             const uint32_t n = lane < nb ? ll : 0u;
-            const uint32_t d0 = o_lit + goff;
-            const uint32_t ndw = (n < 32u ? n : 32u) >> 2;
-            uint32_t wv[8];
+            const uint32_t d0 = o_lit + sneg;
+            uint64_t wv[8];
 #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) wv[k] = cw32(cw, f.ls + 4u * k);
+            for (uint32_t k = 0; k < 8; k++) wv[k] = cw64(cw, ls + 8u * k);
 #pragma unroll
             for (uint32_t k = 0; k < 8; k++)
-              if (k < ndw) ((lds_dp32 *)(stg + ((d0 + 4u * k) & kStgMask)))->v = wv[k];
+              if (8u * k + 8u <= n) ((lds_dp64 *)(stg + d0 + 8u * k))->v = wv[k];
             {
-              // a dword written across the end of the ring left its tail in the pad: bring it round
-              const uint32_t c = kStg - (d0 & kStgMask);  // bytes from the run's start to the end of the ring
-              if ((c & 3u) != 0u && (c >> 2) < ndw) {
-                const uint32_t spill = 4u - (c & 3u);
-                for (uint32_t i = 0; i < spill; i++) stg[i] = stg[kStg + i];
+              // the last 1..7 bytes of a run of up to 64
+              const uint32_t o = n & 0x38u;
+              const uint64_t tv = cw64(cw, ls + o);
+              if (n < 64u) {
+                uint32_t lo32 = (uint32_t)tv, p = d0 + o;
+                if (n & 4u) { ((lds_dp32 *)(stg + p))->v = lo32; p += 4; lo32 = (uint32_t)(tv >> 32); }
+                if (n & 2u) { stg[p] = (uint8_t)lo32; stg[p + 1] = (uint8_t)(lo32 >> 8); p += 2; lo32 >>= 16; }
+                if (n & 1u) stg[p] = (uint8_t)lo32;
               }
             }
-            if (n < 32u) {  // up to three bytes behind the last whole dword
-              const uint32_t tb = n & 3u, o = 4u * ndw;
-              uint32_t bv[3];
-#pragma unroll
-              for (uint32_t i = 0; i < 3; i++) bv[i] = cw8(cw, f.ls + o + i);
-#pragma unroll
-              for (uint32_t i = 0; i < 3; i++)
-                if (i < tb) stg[(d0 + o + i) & kStgMask] = (uint8_t)bv[i];
-            }
-            // what is left of runs longer than 32 bytes: one run after the other, 64 bytes per step
-            for (uint64_t lm = ballot(n > 32u); lm; lm &= lm - 1ull) {
+            // what is left of runs longer than 64 bytes: one run after the other, 64 bytes per step
+            for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
               const uint32_t j = (uint32_t)__builtin_ctzll(lm);
-              const uint32_t s0 = rdlane(f.ls, j) + 32u, dd = rdlane(d0, j) + 32u, len = rdlane(n, j) - 32u;
+              const uint32_t s0 = rdlane(ls, j) + 64u, e0 = rdlane(d0, j) + 64u, len = rdlane(n, j) - 64u;
               for (uint32_t k0 = 0; k0 < len; k0 += kWave) {
                 const uint32_t k = k0 + lane;
-                const uint32_t b = cw8(cw, s0 + k);
-                if (k < len) stg[(dd + k) & kStgMask] = (uint8_t)b;
+                const uint32_t a = s0 + k;
+                const uint32_t b = cw[a < kCw + kCwPad - 1u ? a : kCw + kCwPad - 1u];
+                if (k < len) stg[e0 + k] = (uint8_t)b;
               }
             }
           }
-
           PH(3);
-          // ---- matches in order, ring -> ring.  LDS operations of a wavefront execute in issue order, so a
+
+          // ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a
           // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
           // byte by byte: output byte k is byte k mod dist of the period in front of the match.
-          const uint64_t nearm = ballot(lane < nb && !far);
-          for (uint64_t mm = nearm; mm; mm &= mm - 1ull) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(mm);
-            const uint32_t md = rdlane(o_mat, j) + goff, d = rdlane(dist, j), m = rdlane(ml, j);
-            const uint32_t ms = md - d;
-            uint32_t rr = lane, step = kWave;
-            if (d < m) {  // overlapping: replicate the period
-              if (d < kWave) {
-                rr = lane_mod(lane, d);
-                step = rdlane(rr, kWave - 1u) + 1u;  // 64 mod d
-                if (step == d) step = 0;
+          {
+            const float lanef = (float)lane + 0.5f;
+            u32x2 cur = desc[0];
+            for (uint32_t j = 0; j < nb; j++) {
+              const u32x2 nxt = desc[j + 1u];  // the same address in every lane: a broadcast
+              const uint32_t m = uni(cur.y & 0xffffu);
+              if (m) {
+                const uint32_t d = uni(cur.y >> 16);
+                const uint32_t ms = cur.x & 0xffffu, md = (cur.x >> 16) + lane;
+                uint32_t r = lane, step = kWave, per = 0x40000000u;  // a plain copy never reaches its period
+                if (d < m) {
+                  // r = lane mod d and step = 64 mod d (d > 64: lane and 64); (x + 0.5) / d is at least 1/128 away
+                  // from every integer for x, d <= 64, far more than the reciprocal is off
+                  const float rc = __builtin_amdgcn_rcpf((float)d);
+                  r = lane - __umul24((uint32_t)(lanef * rc), d);
+                  step = 64u - __umul24((uint32_t)(64.5f * rc), d);
+                  per = d;
+                }
+                if (m <= kWave) {
+                  const uint32_t b = stg[ms + r];
+                  if (lane < m) stg[md] = (uint8_t)b;
+                } else {
+                  for (uint32_t k0 = 0; k0 < m; k0 += 2 * kWave) {
+                    const uint32_t ra = r;
+                    r += step;
+                    r = r >= per ? r - per : r;
+                    const uint32_t rb = r;
+                    r += step;
+                    r = r >= per ? r - per : r;
+                    const uint32_t ba = stg[ms + ra], bb = stg[ms + rb];
+                    const uint32_t k = k0 + lane;
+                    if (k < m) stg[md + k0] = (uint8_t)ba;
+                    if (k + kWave < m) stg[md + k0 + kWave] = (uint8_t)bb;
+                  }
+                }
               }
-            } else {
-              // plain copy: never wraps, so the same arithmetic with a period that is never reached
-            }
-            const uint32_t per = d < m ? d : 0x7fffffffu;
-            for (uint32_t k0 = 0; k0 < m; k0 += 4 * kWave) {
-              uint32_t bv[4], ro[4];
-#pragma unroll
-              for (uint32_t u = 0; u < 4; u++) {
-                ro[u] = rr;
-                rr += step;
-                if (rr >= per) rr -= per;
-              }
-#pragma unroll
-              for (uint32_t u = 0; u < 4; u++) {
-                bv[u] = 0;
-                if (k0 + u * kWave < m) bv[u] = stg[(ms + ro[u]) & kStgMask];
-              }
-#pragma unroll
-              for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t k = k0 + u * kWave + lane;
-                if (k0 + u * kWave < m && k < m) stg[(md + k) & kStgMask] = (uint8_t)bv[u];
-              }
+              cur = nxt;
             }
           }
-
           PH(4);
+
           // ---- the batch goes to memory in aligned 16-byte pieces
-          fl = stg_flush(stg, out, goff, fl, b1, false, lane);
+          fl = stg_flush(stg, out, sneg, fl, b1, false, lane);
           op = b1;
           PH(5);
         }
@@ -714,16 +767,42 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     // ---- one sequence through the general loop (and every end of a block)
     PH(7);
     PH_CNT(11);
-    fl = stg_flush(stg, out, goff, fl, op, true, lane);
+    fl = stg_flush(stg, out, sneg, fl, op, true, lane);
     uint32_t di = 0, dn = 0;
     st = decode_run<STRICT, HAS_PREFIX, true>(src + ip, in_end - ip, dst, op_start + op, cap - op, back_limit + op,
                                               prefix, prefix_len, stg, lane, di, dn);
     ip += di;
     op += dn;
     fl = op;
-    vlo = op;  // the general loop used the ring for itself
     PH(6);
     if (st != kSwitchRun) break;
+    // The general loop used the buffer for itself: bring back the history, kH bytes of this block's
+    // output in whole aligned 16-byte pieces, if more sequences follow.
+    sneg = kH + ((op + goff) & 15u) - op;
+    vlo = (int32_t)op;
+    if (in_end - ip >= 8u && op > 0) {
+      // piece c holds positions [16c - sneg, 16c - sneg + 16); the last piece that holds a byte of output is
+      // the one of position op - 1
+      const uint32_t last = (op - 1u + sneg) >> 4;  // <= kH / 16
+      // lowest piece that lies inside the block's output
+      const int32_t sn = (int32_t)sneg;
+      const uint32_t cmin = sn > 0 ? (uint32_t)(sn + 15) >> 4 : 0u;
+      u32x4 v[kH / 1024 + 1];
+#pragma unroll
+      for (uint32_t u = 0; u <= kH / 1024; u++) {
+        const uint32_t c = u * kWave + lane;
+        v[u] = u32x4{0, 0, 0, 0};
+        if (c <= last && c >= cmin) v[u] = *(const u32x4 *)(out + ((int32_t)(16u * c) - sn));
+      }
+#pragma unroll
+      for (uint32_t u = 0; u <= kH / 1024; u++) {
+        const uint32_t c = u * kWave + lane;
+        if (c <= last) *(lds_u128 *)(stg + 16u * c) = v[u];
+      }
+      vm_quiesce();
+      vlo = (int32_t)(16u * cmin) - sn;
+    }
+    PH(6);
   }
   PH_FLUSH(g_dec_phase, lane);
   out_len = op;
@@ -734,11 +813,13 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 // packs into a CU's 160 KiB.
 template <bool STRICT, bool HAS_PREFIX>
 __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStg + kStgPad];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgBytes];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
+  __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
   const uint32_t lane = lane_id();
   lds_u8 *stg = (lds_u8 *)s_stg;
   lds_u8 *cw = (lds_u8 *)s_cw;
+  lds_u64v *desc = (lds_u64v *)s_desc;
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
   const uint32_t prefix_len = a.dict_len;
@@ -760,7 +841,7 @@ __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *count
     if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg,
-                                                        cw, lane, out_len);
+                                                        cw, desc, lane, out_len);
 #ifdef LZ4MI_PROFILE
     if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -776,10 +857,12 @@ __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *count
 // (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
 // serial, so one wavefront walks the blocks in order over one contiguous output.
 __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStg + kStgPad];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgBytes];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
+  __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
   lds_u8 *stg = (lds_u8 *)s_stg;
   lds_u8 *cw = (lds_u8 *)s_cw;
+  lds_u64v *desc = (lds_u64v *)s_desc;
   const uint32_t lane = lane_id();
   uint64_t start = 0;
   uint32_t b = 0;
@@ -794,7 +877,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, lane,
+      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, desc, lane,
                                      produced);
     }
     if (lane == 0) {
