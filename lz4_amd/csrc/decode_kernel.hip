@@ -347,6 +347,8 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 constexpr uint32_t kH = LZ4MI_HIST;         // output bytes kept in LDS in front of a batch (multiple of 1024)
 constexpr uint32_t kBatchOut = LZ4MI_BATCH; // most output bytes of one batch
 constexpr uint32_t kStgBytes = kH + 16 + kBatchOut + 16;  // staging buffer: history, alignment slack, batch, store slack
+constexpr uint32_t kDummy = kStgBytes;      // 64 + 8 bytes behind the buffer that lanes with nothing to write write to
+constexpr uint32_t kStgAlloc = kStgBytes + 80;
 constexpr uint32_t kCw = 2048;              // compressed window in LDS
 constexpr uint32_t kCwPad = 16;
 constexpr uint32_t kCwTop = kCw + kCwPad - 8;   // highest offset an 8-byte read may start at
@@ -377,18 +379,38 @@ __device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
   return ((const lds_dp64 *)(cw + a))->v;
 }
 
-// Parses the byte at window offset a as a token.  The literal length is read with up to seven
-// extension bytes; the match length is taken with ONE extension byte (nx1 = where the next token
-// starts under that assumption), which is all the chain of token starts needs in the common case.
-// A match whose first extension byte is 255 (`mlong`) is finished by seq_match_long.
+// Parses the byte at window offset a as a token, common form: each length with at most one
+// extension byte.  nx1 = where the next token starts in that form, which is all the chain of token
+// starts needs.  `lng`: a length has a second extension byte; seq_long reads such a sequence.
 struct SeqFields {
-  uint32_t ll, ls, q, ml, dist, nx1;  // literal length, window offsets of literals and offset field, match length, distance
-  bool ok, mlong;
+  uint32_t ll, ls, ml, dist, nx;  // literal length, window offset of the literals, match length, distance, next token
+  bool ok, lng;
 };
+__device__ __forceinline__ SeqFields spec_parse(const lds_u8 *cw, uint32_t a, uint32_t wlim) {
+  SeqFields f;
+  const uint32_t t4 = cw32(cw, a);
+  const uint32_t ll0 = (t4 >> 4) & 15u, mc = t4 & 15u, e1 = (t4 >> 8) & 255u;
+  const bool isl = ll0 == 15u, ism = mc == 15u;
+  f.ll = ll0 + (isl ? e1 : 0u);
+  f.ls = a + 1u + (isl ? 1u : 0u);
+  const uint32_t q = f.ls + f.ll;
+  const uint32_t o4 = cw32(cw, q);
+  const uint32_t f1 = (o4 >> 16) & 255u;
+  f.dist = o4 & 0xffffu;
+  f.ml = mc + 4u + (ism ? f1 : 0u);
+  f.nx = q + 2u + (ism ? 1u : 0u);
+  const bool llong = isl && e1 == 255u;
+  f.lng = llong || (ism && f1 == 255u);
+  // the header as far as it was read lies inside the window (a long literal run: its first extension byte does)
+  f.ok = (llong ? a + 2u : f.nx) <= wlim;
+  return f;
+}
 __device__ __forceinline__ uint32_t ff_bytes(uint64_t x) {  // bytes of 0xFF at the low end of x (x has a byte that is not)
   return (uint32_t)__builtin_ctzll(~x) >> 3;
 }
-__device__ __forceinline__ SeqFields spec_parse(const lds_u8 *cw, uint32_t a, uint32_t wlim) {
+// The same for any sequence the batch takes: up to seven extension bytes of the literal length, up
+// to six of the match length.  ok: within those limits and inside the window.
+__device__ __forceinline__ SeqFields seq_long(const lds_u8 *cw, uint32_t a, uint32_t wlim) {
   SeqFields f;
   const uint64_t t8 = cw64(cw, a);
   const uint32_t tok = (uint32_t)t8 & 255u;
@@ -399,29 +421,17 @@ __device__ __forceinline__ SeqFields spec_parse(const lds_u8 *cw, uint32_t a, ui
   const uint32_t eb = (uint32_t)(ext >> (8u * (nff & 7u))) & 255u;
   f.ll = isl ? 15u + 255u * nff + eb : ll0;
   f.ls = a + 1u + (isl ? nff + 1u : 0u);
-  f.q = f.ls + f.ll;
-  const uint32_t o4 = cw32(cw, f.q);
-  const uint32_t f1 = (o4 >> 16) & 255u;
-  f.dist = o4 & 0xffffu;
-  f.ml = mc + 4u + (ism ? f1 : 0u);
-  f.nx1 = f.q + 2u + (ism ? 1u : 0u);
-  f.mlong = ism && f1 == 255u;
-  // the closing byte of the literal length is one of the seven read, and the header as far as it was
-  // read lies inside the window
-  f.ok = !(isl && nff == 7u) && f.nx1 <= wlim;
-  return f;
-}
-// Match length and next-token offset of a sequence whose match length has two or more extension bytes
-// (q = window offset of its offset field).  ok: at most six extension bytes, all inside the window.
-__device__ __forceinline__ void seq_match_long(const lds_u8 *cw, uint32_t q, uint32_t wlim, uint32_t &ml, uint32_t &nx,
-                                               bool &ok) {
+  const uint32_t q = f.ls + f.ll;
   const uint64_t o8 = cw64(cw, q);
-  const uint64_t ext = o8 >> 16;                            // six extension bytes, then zero bytes
-  const uint32_t nff = ff_bytes(ext);                       // >= 1 here
-  const uint32_t eb = (uint32_t)(ext >> (8u * (nff & 7u))) & 255u;
-  ml = 19u + 255u * nff + eb;
-  nx = q + 2u + nff + 1u;
-  ok = nff < 6u && nx <= wlim;
+  f.dist = (uint32_t)o8 & 0xffffu;
+  const uint64_t mext = o8 >> 16;                          // six extension bytes, then zero bytes
+  const uint32_t mff = ff_bytes(mext);
+  const uint32_t mb = (uint32_t)(mext >> (8u * (mff & 7u))) & 255u;
+  f.ml = ism ? 19u + 255u * mff + mb : mc + 4u;
+  f.nx = q + 2u + (ism ? mff + 1u : 0u);
+  f.lng = false;
+  f.ok = !(isl && nff == 7u) && !(ism && mff == 6u) && f.nx <= wlim;
+  return f;
 }
 
 // Loads kCw bytes of the block, starting at the 16-byte aligned address at or below src + ip, into the
@@ -465,14 +475,14 @@ __device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, u
   for (uint32_t c0 = 0; c0 < pieces; c0 += 4 * kWave) {
     u32x4 v[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; u++) {
+    for (uint32_t u = 0; u < 4; u++) {  // lanes past the end store the last piece again
       const uint32_t c = c0 + u * kWave + lane;
-      v[u] = *(const lds_u128 *)(stg + from + sneg + 16u * (c < pieces ? c : 0u));
+      v[u] = *(const lds_u128 *)(stg + from + sneg + 16u * (c < pieces ? c : pieces - 1u));
     }
 #pragma unroll
     for (uint32_t u = 0; u < 4; u++) {
       const uint32_t c = c0 + u * kWave + lane;
-      if (c < pieces) *(u32x4 *)(out + from + 16u * c) = v[u];
+      *(u32x4 *)(out + from + 16u * (c < pieces ? c : pieces - 1u)) = v[u];
     }
   }
   from += 16u * pieces;
@@ -535,43 +545,41 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       uint32_t cb = ip - (uint32_t)wb, r = 0, count = 0, tot = 0;
       bool notok = false;
       for (;;) {
-        const SeqFields f = spec_parse(cw, cb + lane, wlim);
-        const uint32_t nx = f.nx1 - cb;
+        SeqFields f = spec_parse(cw, cb + lane, wlim);
+        const uint32_t nx = f.nx - cb;
         const uint64_t okm = ballot(f.ok);
         uint64_t starts = 0;
         for (;;) {
           if (!((okm >> r) & 1ull)) { notok = true; break; }
           starts |= 1ull << r;
+          tot += rdlane(f.ll, r) + 64u;  // a guess for the match; the exact sum is taken when the batch is cut
           r = rdlane(nx, r);
           if (r >= kWave) break;
         }
-        uint32_t ml = f.ml;
-        const uint64_t lm = ballot(f.mlong) & starts;
+        const uint64_t lm = ballot(f.lng) & starts;
         if (lm) {
-          // the first start with a long match ends this chunk: its real length and successor are read now
+          // the first start in a long form ends this chunk: its real lengths and successor are read now
           const uint32_t h = (uint32_t)__builtin_ctzll(lm);
-          uint32_t mlx, nxx;
-          bool okx;
-          seq_match_long(cw, f.q, wlim, mlx, nxx, okx);
-          starts &= (2ull << h) - 1ull;
-          notok = false;
-          r = rdlane(nxx, h) - cb;
-          if (!((ballot(okx) >> h) & 1ull)) {  // not a batched sequence after all
+          const SeqFields g = seq_long(cw, cb + lane, wlim);
+          if ((ballot(g.ok) >> h) & 1ull) {
+            starts &= (2ull << h) - 1ull;
+            notok = false;
+            r = rdlane(g.nx, h) - cb;
+            tot += rdlane(g.ll + g.ml, h);
+            if (lane == h) f = g;
+          } else {  // not a sequence for the batch after all
             starts &= (1ull << h) - 1ull;
             notok = true;
             r = h;
           }
-          if (lane == h) ml = mlx;
         }
-        const bool st_lane = (starts >> lane) & 1ull;
-        if (st_lane) {
+        {
           u32x2 d;
           d.x = f.ls | (f.ll << 16);
-          d.y = ml | (f.dist << 16);
-          desc[count + mbcnt64(starts)] = d;
+          d.y = f.ml | (f.dist << 16);
+          desc[(starts >> lane) & 1ull ? count + mbcnt64(starts) : kDesc - 1u] = d;
         }
         count += (uint32_t)__builtin_popcountll(starts);
-        tot += rdlane(wave_incl_scan(st_lane ? f.ll + ml : 0u), kWave - 1u);
         if (notok || count > kWave - 22u || tot > kBatchOut - 512u) break;
         cb += r;
         r = 0;
@@ -619,13 +627,13 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         const uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
         far = far && lane < nb;
         const bool near = lane < nb && !far;
-        {
-          u32x2 d;  // match descriptor: source and destination as buffer offsets, length (0: nothing to do), distance
-          d.x = ((uint32_t)sp + sneg) | ((o_mat + sneg) << 16);
-          d.y = (near ? ml : 0u) | (dist << 16);
-          desc[lane] = d;
-          if (lane == 0) desc[kWave] = u32x2{0u, 0u};
-        }
+        // match descriptors: source and destination as buffer offsets; length (0: nothing to do here) and distance
+        const uint32_t vA = (((uint32_t)sp + sneg) & 0xffffu) | ((o_mat + sneg) << 16);
+        const uint32_t vB = (near ? ml : 0u) | (dist << 16);
+        // lane mod dist without a division in the copy loop: q = (lane * mg) >> 16 is lane / dist for lane < 64
+        // (mg = 65536 / dist + 1 is off by less than 1 / dist over that range); step = 64 mod dist
+        const uint32_t dsafe = dist ? dist : 1u;
+        const uint32_t vC = (65536u / dsafe + 1u) | ((64u % dsafe) << 17);
         PH(1);
         if (nb) {
 #ifdef LZ4MI_PROFILE
@@ -652,12 +660,10 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 #pragma unroll
               for (uint32_t t = 0; t < kFarMax / kWave; t++) {
                 v[u][t] = 0;
-                if (t * kWave < fn[u]) {
-                  const uint32_t idx = t * kWave + lane;
-                  if (idx < fn[u]) {
-                    const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
-                    v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
-                  }
+                if (t * kWave < fn[u]) {  // lanes past the end read the last byte again
+                  const uint32_t idx = t * kWave + lane < fn[u] ? t * kWave + lane : fn[u] - 1u;
+                  const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
+                  v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
                 }
               }
             }
@@ -667,7 +673,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
               for (uint32_t t = 0; t < kFarMax / kWave; t++) {
                 if (t * kWave < fn[u]) {
                   const uint32_t idx = t * kWave + lane;
-                  if (idx < fn[u]) stg[fd[u] + idx] = (uint8_t)v[u][t];
+                  stg[idx < fn[u] ? fd[u] + idx : kDummy + lane] = (uint8_t)v[u][t];
                 }
               }
             }
@@ -675,36 +681,43 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           }
           PH(2);
 
-          // ---- literals: lane j copies its run, window -> buffer, eight bytes at a time
+          // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
+          // off (that costs more than the copies): a run of 8 bytes or more goes in 8-byte pieces whose
+          // offsets are clamped to length - 8, so the last pieces overlap; runs of 4..7 bytes in two
+          // overlapping dwords; shorter ones byte by byte; what does not apply writes to a dummy slot.
           {
             const uint32_t n = lane < nb ? ll : 0u;
             const uint32_t d0 = o_lit + sneg;
-            uint64_t wv[8];
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) wv[k] = cw64(cw, ls + 8u * k);
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++)
-              if (8u * k + 8u <= n) ((lds_dp64 *)(stg + d0 + 8u * k))->v = wv[k];
             {
-              // the last 1..7 bytes of a run of up to 64
-              const uint32_t o = n & 0x38u;
-              const uint64_t tv = cw64(cw, ls + o);
-              if (n < 64u) {
-                uint32_t lo32 = (uint32_t)tv, p = d0 + o;
-                if (n & 4u) { ((lds_dp32 *)(stg + p))->v = lo32; p += 4; lo32 = (uint32_t)(tv >> 32); }
-                if (n & 2u) { stg[p] = (uint8_t)lo32; stg[p + 1] = (uint8_t)(lo32 >> 8); p += 2; lo32 >>= 16; }
-                if (n & 1u) stg[p] = (uint8_t)lo32;
+              const bool use8 = n >= 8u;
+              const uint32_t top = (n < 64u ? n : 64u) - 8u;
+              uint64_t wv[8];
+              uint32_t o[8];
+#pragma unroll
+              for (uint32_t k = 0; k < 8; k++) {
+                o[k] = 8u * k < top ? 8u * k : top;
+                wv[k] = cw64(cw, ls + (use8 ? o[k] : 0u));
               }
+#pragma unroll
+              for (uint32_t k = 0; k < 8; k++) ((lds_dp64 *)(stg + (use8 ? d0 + o[k] : kDummy + 64u)))->v = wv[k];
             }
-            // what is left of runs longer than 64 bytes: one run after the other, 64 bytes per step
+            {
+              const bool use4 = n >= 4u && n < 8u;
+              const uint32_t w0 = cw32(cw, ls), w1 = cw32(cw, ls + (use4 ? n - 4u : 0u));
+              ((lds_dp32 *)(stg + (use4 ? d0 : kDummy + 64u)))->v = w0;
+              ((lds_dp32 *)(stg + (use4 ? d0 + n - 4u : kDummy + 64u)))->v = w1;
+              const uint32_t b3 = cw32(cw, ls);
+#pragma unroll
+              for (uint32_t i = 0; i < 3; i++) stg[n < 4u && i < n ? d0 + i : kDummy + lane] = (uint8_t)(b3 >> (8u * i));
+            }
+            // runs longer than 64 bytes, one after the other: bytes 56.. in 8-byte pieces, 512 bytes per step,
+            // clamped the same way (at least 9 bytes are left, so a piece always fits)
             for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
               const uint32_t j = (uint32_t)__builtin_ctzll(lm);
-              const uint32_t s0 = rdlane(ls, j) + 64u, e0 = rdlane(d0, j) + 64u, len = rdlane(n, j) - 64u;
-              for (uint32_t k0 = 0; k0 < len; k0 += kWave) {
-                const uint32_t k = k0 + lane;
-                const uint32_t a = s0 + k;
-                const uint32_t b = cw[a < kCw + kCwPad - 1u ? a : kCw + kCwPad - 1u];
-                if (k < len) stg[e0 + k] = (uint8_t)b;
+              const uint32_t s0 = rdlane(ls, j) + 56u, e0 = rdlane(d0, j) + 56u, top = rdlane(n, j) - 64u;  // len - 8
+              for (uint32_t k0 = 0; k0 < top + 8u; k0 += 8 * kWave) {  // the last step has a lane at or past `top`
+                const uint32_t o = k0 + 8u * lane < top ? k0 + 8u * lane : top;
+                ((lds_dp64 *)(stg + e0 + o))->v = cw64(cw, s0 + o);
               }
             }
           }
@@ -713,43 +726,21 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           // ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a
           // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
           // byte by byte: output byte k is byte k mod dist of the period in front of the match.
-          {
-            const float lanef = (float)lane + 0.5f;
-            u32x2 cur = desc[0];
-            for (uint32_t j = 0; j < nb; j++) {
-              const u32x2 nxt = desc[j + 1u];  // the same address in every lane: a broadcast
-              const uint32_t m = uni(cur.y & 0xffffu);
-              if (m) {
-                const uint32_t d = uni(cur.y >> 16);
-                const uint32_t ms = cur.x & 0xffffu, md = (cur.x >> 16) + lane;
-                uint32_t r = lane, step = kWave, per = 0x40000000u;  // a plain copy never reaches its period
-                if (d < m) {
-                  // r = lane mod d and step = 64 mod d (d > 64: lane and 64); (x + 0.5) / d is at least 1/128 away
-                  // from every integer for x, d <= 64, far more than the reciprocal is off
-                  const float rc = __builtin_amdgcn_rcpf((float)d);
-                  r = lane - __umul24((uint32_t)(lanef * rc), d);
-                  step = 64u - __umul24((uint32_t)(64.5f * rc), d);
-                  per = d;
-                }
-                if (m <= kWave) {
-                  const uint32_t b = stg[ms + r];
-                  if (lane < m) stg[md] = (uint8_t)b;
-                } else {
-                  for (uint32_t k0 = 0; k0 < m; k0 += 2 * kWave) {
-                    const uint32_t ra = r;
-                    r += step;
-                    r = r >= per ? r - per : r;
-                    const uint32_t rb = r;
-                    r += step;
-                    r = r >= per ? r - per : r;
-                    const uint32_t ba = stg[ms + ra], bb = stg[ms + rb];
-                    const uint32_t k = k0 + lane;
-                    if (k < m) stg[md + k0] = (uint8_t)ba;
-                    if (k + kWave < m) stg[md + k0 + kWave] = (uint8_t)bb;
-                  }
-                }
-              }
-              cur = nxt;
+          // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
+          for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t B = rdlane(vB, j);
+            const uint32_t m = B & 0xffffu;
+            if (!m) continue;
+            const uint32_t d = B >> 16, A = rdlane(vA, j), C = rdlane(vC, j);
+            const uint32_t ms = A & 0xffffu, md = (A >> 16) + lane;
+            const uint32_t per = d < m ? d : 0x40000000u;  // a plain copy never reaches its period
+            const uint32_t step = d < m ? C >> 17 : kWave;
+            uint32_t r = lane - __umul24(__umul24(lane, C & 0x1ffffu) >> 16, d);  // lane mod d
+            for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
+              const uint32_t v = stg[ms + r];
+              stg[k0 + lane < m ? md + k0 : kDummy + lane] = (uint8_t)v;
+              r += step;
+              r = r >= per ? r - per : r;
             }
           }
           PH(4);
@@ -813,7 +804,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 // packs into a CU's 160 KiB.
 template <bool STRICT, bool HAS_PREFIX>
 __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
   const uint32_t lane = lane_id();
@@ -857,7 +848,7 @@ __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *count
 // (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
 // serial, so one wavefront walks the blocks in order over one contiguous output.
 __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgBytes];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
   lds_u8 *stg = (lds_u8 *)s_stg;
