@@ -29,6 +29,9 @@ namespace lz4mi {
 
 #ifdef LZ4MI_PROFILE
 __device__ unsigned long long g_dec_phase[PH_SLOTS];
+#endif
+#if defined(LZ4MI_PROFILE) || defined(LZ4MI_SPANS)
+#define LZ4MI_DEC_SPANS 1
 __device__ unsigned long long g_dec_span[2 * 65536];  // per block: start and end (100 MHz ticks)
 #endif
 
@@ -179,7 +182,7 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   vm_quiesce();
 }
 
-constexpr uint32_t kRing = 8192;   // bytes of recent output the general loop mirrors in LDS
+constexpr uint32_t kRing = 4096;   // bytes of recent output the general loop mirrors in LDS
 constexpr uint32_t kShort = 256;   // copies up to this length go through its ring path
 
 // ---------------------------------------------------------------------------------------------
@@ -342,7 +345,7 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 #define LZ4MI_HIST 4096
 #endif
 #ifndef LZ4MI_BATCH
-#define LZ4MI_BATCH 4096
+#define LZ4MI_BATCH 3584
 #endif
 constexpr uint32_t kH = LZ4MI_HIST;         // output bytes kept in LDS in front of a batch (multiple of 1024)
 constexpr uint32_t kBatchOut = LZ4MI_BATCH; // most output bytes of one batch
@@ -357,7 +360,7 @@ constexpr uint32_t kMatMax = 19 + 5 * 255 + 254;  // longest match (up to six ex
 constexpr uint32_t kSeqIn = 8 + kLitMax + 8 + 8;  // compressed bytes a batched sequence may span, plus slack
 constexpr uint32_t kSeqTyp = 320;           // a window with fewer bytes than this behind ip is not worth a parse
 constexpr uint32_t kFarMax = 320;           // bytes per match the out-of-buffer path fetches (5 steps of 64)
-constexpr uint32_t kDesc = 65;              // sequence descriptors (8 bytes each): one per lane and a spare
+constexpr uint32_t kTl = 136;               // token list entries (two bytes each): 64 tokens, a spare, the dummy slot at 128
 static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at least one sequence");
 static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
 static_assert(kH % 1024 == 0, "layout");
@@ -368,6 +371,7 @@ typedef __attribute__((address_space(3))) DP32 lds_dp32;
 typedef __attribute__((address_space(3))) DP64 lds_dp64;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2 lds_u64v;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 // bytes at window offset a (clamped: a read past the window returns bytes that no caller uses)
 __device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
@@ -497,7 +501,7 @@ template <bool STRICT, bool HAS_PREFIX>
 __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                 const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                 const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                                lds_u8 *stg, lds_u8 *cw, lds_u64v *desc, uint32_t lane, uint32_t &out_len) {
+                                                lds_u8 *stg, lds_u8 *cw, lds_u16 *tl, uint32_t lane, uint32_t &out_len) {
   const uint32_t in_end = src_len;
   uint8_t *const out = dst + op_start;
   const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
@@ -508,6 +512,8 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   int32_t wb = 0;
   uint32_t wlim = 0;
   bool have_win = false;
+  bool dense = false;     // token chain: tokens are close together (chunk steps) or far apart (scalar steps)
+  uint32_t shortrun = 0;  // scalar steps in a row that were short
   int32_t st = LZ4MI_OK;
   PH_DECL
 
@@ -521,6 +527,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         have_win = true;
         PH_CNT(13);
       }
+      PH(12);
       // ---- slide the buffer so that the batch starts right behind kH bytes of history
       {
         const uint32_t shift = (op + sneg - kH) & ~15u;  // op + sneg >= kH always
@@ -539,68 +546,85 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           sneg -= shift;
         }
       }
-      // ---- chain of token starts: lane p of a 64-byte chunk parses byte cb + p as a token; the real
-      // starts are followed with one cross-lane read each and noted in a bit mask; the lanes that stand
-      // on a start put their fields into the descriptor list
-      uint32_t cb = ip - (uint32_t)wb, r = 0, count = 0, tot = 0;
-      bool notok = false;
-      for (;;) {
-        SeqFields f = spec_parse(cw, cb + lane, wlim);
-        const uint32_t nx = f.nx - cb;
-        const uint64_t okm = ballot(f.ok);
-        uint64_t starts = 0;
-        for (;;) {
-          if (!((okm >> r) & 1ull)) { notok = true; break; }
-          starts |= 1ull << r;
-          tot += rdlane(f.ll, r) + 64u;  // a guess for the match; the exact sum is taken when the batch is cut
-          r = rdlane(nx, r);
-          if (r >= kWave) break;
+      PH(14);
+      // ---- chain of token starts.  Only where the tokens are is found here, under the assumption that no
+      // match length has a second extension byte; the positions go into a list, lane j then reads sequence j
+      // in full, and a sequence whose real successor is not the next position of the list ends the batch.
+      // Two ways to step: where tokens are dense, lane p of a 64-byte chunk parses byte a + p as a token
+      // and the real starts are followed with one cross-lane read each; where literal runs are long (one
+      // token per chunk), the token is read into scalar registers and parsed there.
+      uint32_t a = ip - (uint32_t)wb, count = 0, tot = 0;
+      bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
+      while (count < kWave && tot <= kBatchOut - 512u) {
+        if (dense && count <= kWave - 22u) {
+          const uint32_t t4 = cw32(cw, a + lane);
+          const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
+          const bool isl = ll0 == 15u;
+          const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
+          const uint64_t okm = ballot(a + nx <= wlim && !(isl && e1 == 255u));
+          uint64_t starts = 0;
+          uint32_t r = 0;
+          bool notok = false;
+          for (;;) {
+            if (!((okm >> r) & 1ull)) { notok = true; break; }
+            starts |= 1ull << r;
+            r = rdlane(nx, r);
+            if (r >= kWave) break;
+          }
+          tl[(starts >> lane) & 1ull ? count + mbcnt64(starts) : 2u * kWave] = (uint16_t)(a + lane);
+          const uint32_t n = (uint32_t)__builtin_popcountll(starts);
+          count += n;
+          tot += r + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
+          a += r;
+          dense = n >= 2u && !notok;
+          continue;
         }
-        const uint64_t lm = ballot(f.lng) & starts;
-        if (lm) {
-          // the first start in a long form ends this chunk: its real lengths and successor are read now
-          const uint32_t h = (uint32_t)__builtin_ctzll(lm);
-          const SeqFields g = seq_long(cw, cb + lane, wlim);
-          if ((ballot(g.ok) >> h) & 1ull) {
-            starts &= (2ull << h) - 1ull;
-            notok = false;
-            r = rdlane(g.nx, h) - cb;
-            tot += rdlane(g.ll + g.ml, h);
-            if (lane == h) f = g;
-          } else {  // not a sequence for the batch after all
-            starts &= (1ull << h) - 1ull;
-            notok = true;
-            r = h;
+        // one token, in scalar registers
+        if (a + 4u > wlim) { stopped = true; break; }
+        const uint64_t t8v = cw64(cw, a);
+        const uint32_t lo = uni((uint32_t)t8v), hi = uni((uint32_t)(t8v >> 32));
+        const uint32_t ll0 = (lo >> 4) & 15u;
+        uint32_t ll = ll0, xl = 0;
+        if (ll0 == 15u) {
+          const uint32_t e1 = (lo >> 8) & 255u;
+          ll = 15u + e1;
+          xl = 1;
+          if (e1 == 255u) {  // up to seven extension bytes
+            const uint64_t ext = (((uint64_t)hi << 32) | lo) >> 8;
+            const uint32_t nff = ff_bytes(ext);
+            if (nff == 7u) { stopped = true; break; }
+            ll = 15u + 255u * nff + ((uint32_t)(ext >> (8u * nff)) & 255u);
+            xl = nff + 1u;
           }
         }
-        {
-          u32x2 d;
-          d.x = f.ls | (f.ll << 16);
-          d.y = f.ml | (f.dist << 16);
-          desc[(starts >> lane) & 1ull ? count + mbcnt64(starts) : kDesc - 1u] = d;
-        }
-        count += (uint32_t)__builtin_popcountll(starts);
-        if (notok || count > kWave - 22u || tot > kBatchOut - 512u) break;
-        cb += r;
-        r = 0;
+        const uint32_t nx = a + 1u + xl + ll + 2u + ((lo & 15u) == 15u ? 1u : 0u);
+        if (nx > wlim) { stopped = true; break; }
+        tl[count] = (uint16_t)a;
+        count++;
+        tot += ll + 64u;
+        shortrun = nx - a < 24u ? shortrun + 1u : 0u;
+        dense = shortrun >= 2u;
+        a = nx;
       }
-      uint32_t ip_stop = (uint32_t)wb + cb + r;
-      if (notok) {
-        // a length with too many extension bytes, the end of the block, or the end of the window.  A window
-        // that was loaded at this token holds any sequence the batch takes, so there it is not the window.
-        general = (uint32_t)(wb + (int32_t)kCw) >= in_end || cb + r < 16u;
-        if (!general) have_win = false;
-      } else {
-        general = false;
-      }
+      uint32_t ip_stop = (uint32_t)wb + a;
+      // A token that ends the chain: too many extension bytes, the end of the block, or the end of the window.
+      // A window that was loaded at this token holds any sequence the batch takes, so there it is not the window.
+      general = stopped && ((uint32_t)(wb + (int32_t)kCw) >= in_end || a < 16u);
+      if (stopped && !general) have_win = false;
       PH(0);
 
       if (count) {
         // ---- lane j owns sequence j
-        const u32x2 dd = desc[lane < count ? lane : 0u];
         const bool mine = lane < count;
-        const uint32_t ls = dd.x & 0xffffu, ll = mine ? dd.x >> 16 : 0u;
-        const uint32_t ml = mine ? dd.y & 0xffffu : 0u, dist = dd.y >> 16;
+        const uint32_t ta = tl[lane], tn = tl[lane + 1u];
+        const SeqFields g = seq_long(cw, ta, wlim);
+        const uint32_t ls = g.ls, ll = mine ? g.ll : 0u, ml = mine ? g.ml : 0u, dist = g.dist;
+        // the sequences in front of the first one that is not for the batch, or whose successor is not the
+        // next token of the list, are real
+        const uint64_t nokm = ballot(mine && !g.ok), brkm = ballot(mine && lane + 1u < count && g.nx != tn);
+        const uint32_t nnok = nokm ? (uint32_t)__builtin_ctzll(nokm) : kWave;
+        const uint32_t nbrk = brkm ? (uint32_t)__builtin_ctzll(brkm) + 1u : kWave;
+        const uint32_t nreal = nnok < nbrk ? (nnok < count ? nnok : count) : (nbrk < count ? nbrk : count);
         const uint32_t incl = wave_incl_scan(ll + ml);
         const uint32_t o_lit = op + incl - (ll + ml);  // where the literals go
         const uint32_t o_mat = o_lit + ll;             // where the match goes
@@ -613,16 +637,30 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         // an out-of-buffer source that is longer than the fetch below takes, or that reaches into output
         // not yet in memory (possible right after the general loop): general loop
         const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
-        const uint64_t badm = ballot(bad), overm = ballot(mine && incl > kBatchOut);
+        const uint64_t realm = nreal < kWave ? (1ull << nreal) - 1ull : ~0ull;
+        const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > kBatchOut) & realm;
         const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
         const uint32_t nover = overm ? (uint32_t)__builtin_ctzll(overm) : kWave;
-        uint32_t nb = count;
-        if (nbad < nb || nover < nb) {
+        uint32_t nb = nreal;
+        if (nbad < nb || nover < nb) {  // a sequence that fails a check, or the batch is full
           nb = nbad < nover ? nbad : nover;
           general = nbad <= nover;
           have_win = true;
-          const uint32_t lsn = rdlane(ls, nb), lln = rdlane(dd.x >> 16, nb);
-          ip_stop = (uint32_t)wb + lsn - 1u - (lln >= 15u ? (lln - 15u) / 255u + 1u : 0u);
+          ip_stop = (uint32_t)wb + rdlane(ta, nb);
+        } else if (nreal < count && nnok <= nbrk) {  // a token that is not for the batch
+          const uint32_t at = rdlane(ta, nreal);
+          ip_stop = (uint32_t)wb + at;
+          general = (uint32_t)(wb + (int32_t)kCw) >= in_end || at < 16u;
+          have_win = general;
+        } else {
+          // the chain went on behind a match with more extension bytes than it assumed (then the rest of the list
+          // is void), or the list is used up: go on at the real successor of the last sequence taken
+          const uint32_t nxl = rdlane(g.nx, nb - 1u);
+          if (nreal < count || nxl != a) {
+            general = false;
+            have_win = true;
+          }
+          ip_stop = (uint32_t)wb + nxl;
         }
         const uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
         far = far && lane < nb;
@@ -803,14 +841,14 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 // One wavefront per workgroup: a wavefront's LDS (ring + window) is then the unit the hardware
 // packs into a CU's 160 KiB.
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
-  __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
+  __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
   const uint32_t lane = lane_id();
   lds_u8 *stg = (lds_u8 *)s_stg;
   lds_u8 *cw = (lds_u8 *)s_cw;
-  lds_u64v *desc = (lds_u64v *)s_desc;
+  lds_u16 *tl = (lds_u16 *)s_tl;
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
   const uint32_t prefix_len = a.dict_len;
@@ -828,12 +866,12 @@ __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *count
     uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
     const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
     uint32_t out_len = 0;
-#ifdef LZ4MI_PROFILE
+#ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     const int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg,
-                                                        cw, desc, lane, out_len);
-#ifdef LZ4MI_PROFILE
+                                                        cw, tl, lane, out_len);
+#ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (lane == 0) {
@@ -850,10 +888,10 @@ __global__ __launch_bounds__(64) void decode_kernel(BatchArgs a, uint32_t *count
 __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
-  __shared__ __attribute__((aligned(16))) u32x2 s_desc[kDesc];
+  __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
   lds_u8 *stg = (lds_u8 *)s_stg;
   lds_u8 *cw = (lds_u8 *)s_cw;
-  lds_u64v *desc = (lds_u64v *)s_desc;
+  lds_u16 *tl = (lds_u16 *)s_tl;
   const uint32_t lane = lane_id();
   uint64_t start = 0;
   uint32_t b = 0;
@@ -868,7 +906,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, desc, lane,
+      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, tl, lane,
                                      produced);
     }
     if (lane == 0) {
@@ -884,10 +922,12 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
   }
 }
 
-#ifdef LZ4MI_PROFILE
+#ifdef LZ4MI_DEC_SPANS
 extern "C" void lz4mi_debug_dec_spans(unsigned long long *out, int n) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_span), sizeof(unsigned long long) * 2 * n);
 }
+#endif
+#ifdef LZ4MI_PROFILE
 extern "C" void lz4mi_debug_dec_phases(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_phase), sizeof(unsigned long long) * PH_SLOTS);
   if (reset) {

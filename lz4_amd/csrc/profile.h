@@ -27,7 +27,6 @@ __device__ __forceinline__ __attribute__((address_space(3))) uint32_t *ph_column
 #define PH_FLUSH(arr, lane)                                                                          \
   do {                                                                                               \
     ph_c_[15 * 64] = (uint32_t)(__builtin_readcyclecounter() - ph_t0_);                              \
-    ph_c_[12 * 64] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - ph_r0_);                          \
     if ((lane) == 0)                                                                                 \
       for (int q_ = 0; q_ < PH_SLOTS; q_++)                                                          \
         if (ph_c_[q_ * 64]) atomicAdd(&(arr)[q_], (unsigned long long)ph_c_[q_ * 64]);               \

@@ -15,7 +15,8 @@ for _ in range(2):
     out, ol, st2 = codec.decompress_blocks(slots, sizes, 65536, strict=True)
 torch.cuda.synchronize()
 heavy = np.isin(np.arange(NB) % 8, (5, 6))
-for name, fn in (('enc', L.lz4mi_debug_enc_spans), ('dec', L.lz4mi_debug_dec_spans)):
+which = sys.argv[1:] or ['enc', 'dec']
+for name, fn in [(w, getattr(L, 'lz4mi_debug_%s_spans' % w)) for w in which]:
     buf = np.zeros(2 * NB, dtype=np.uint64)
     fn(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)), NB)
     t0 = buf[0::2].astype(np.float64); t1 = buf[1::2].astype(np.float64)
@@ -30,7 +31,7 @@ for name, fn in (('enc', L.lz4mi_debug_enc_spans), ('dec', L.lz4mi_debug_dec_spa
     top = np.argsort(-d)[:5]
     print("  longest:", [(int(i), int(i) % 8, round(float(s[i])), round(float(d[i]))) for i in top])
     # how many blocks are running over time
-    for t in (100, 300, 500, 800, 1000, 1500, 2000, 2500):
+    for t in (50, 100, 200, 300, 400, 500, 600, 800, 1000, 1500, 2000, 2500):
         print(f"    t={t}: running {(int(((s<=t)&(e>t)).sum()))} heavy running {int(((s<=t)&(e>t)&heavy).sum())} not started {int((s>t).sum())}")
     cls = np.arange(NB) % 8
     print("  per class mean/max duration us:", {int(c): (round(float(d[cls == c].mean())), round(float(d[cls == c].max()))) for c in range(8)})

@@ -8,9 +8,9 @@ from tools.corpus import corpus_block
 codec = DeviceCodec(0)
 L = N.load()
 NB = int(__import__('os').environ.get('NB', '1024'))
-names = ['0 window + token chain', '1 lane fields, scan, checks', '2 out-of-ring matches', '3 literals', '4 matches', '5 flush',
+names = ['0 token chain', '1 lane fields, scan, checks', '2 out-of-ring matches', '3 literals', '4 matches', '5 flush',
          '6 general loop', '7 other', '8 #batches', '9 #batched sequences', '10 #out-of-ring matches', '11 #general steps',
-         '12 realtime ticks (100 MHz)', '13 #window loads', '14', '15 total cycles']
+         '12 window load', '13 #window loads', '14 buffer slide', '15 total cycles']
 for arg in sys.argv[1:] or ['5']:
     idx = [int(x) for x in arg.split(',')]
     blocks = [corpus_block(i) for i in idx]
@@ -25,7 +25,7 @@ for arg in sys.argv[1:] or ['5']:
     v = list(buf)
     print(f'blocks {idx}: {e0.elapsed_time(e1):.3f} ms for {NB} blocks', flush=True)
     for i, nm in enumerate(names):
-        if i >= 8:
+        if 8 <= i <= 11 or i == 13:
             print(f'   {nm:28s} {v[i] / NB:10.1f} per block')
         elif i == 15:
             print(f'   {nm:28s} {v[i] / NB / 1000:10.1f} kticks per block')

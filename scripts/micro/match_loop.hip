@@ -15,6 +15,8 @@ __global__ __launch_bounds__(64) void k(uint64_t *out, uint32_t *sink, const uin
   for (uint32_t i = lane; i < 8224 + 64; i += 64) buf[i] = (uint8_t)(i * 7);
   __syncthreads();
   const uint32_t vA = dA[lane], vB = dB[lane];
+  const uint32_t dsafe_ = (vB >> 16) ? (vB >> 16) : 1u;
+  const uint32_t vC = (65536u / dsafe_ + 1u) | ((64u % dsafe_) << 17);
   const uint32_t nb = 64;
   const float lanef = (float)lane + 0.5f;
   uint64_t t0 = __builtin_readcyclecounter();
@@ -140,6 +142,51 @@ __global__ __launch_bounds__(64) void k(uint64_t *out, uint32_t *sink, const uin
           r += d < m ? step : 64u; r = r >= per ? r - per : r;
         }
       }
+    } else if (V == 7) {  // magic modulo, two pieces straight-line, loop only past 128 bytes, no skip branch
+      for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t B = rdlane(vB, j), A = rdlane(vA, j), C = rdlane(vC, j);
+        const uint32_t m = B & 0xffffu, d = B >> 16;
+        const uint32_t ms = A & 0xffffu, md = (A >> 16) + lane;
+        const uint32_t per = d < m ? d : 0x40000000u;
+        const uint32_t step = d < m ? C >> 17 : 64u;
+        uint32_t r = lane - __umul24(__umul24(lane, C & 0x1ffffu) >> 16, d);
+        uint32_t r2 = r + step; r2 = r2 >= per ? r2 - per : r2;
+        const uint32_t va = stg[ms + r], vb = stg[ms + r2];
+        stg[lane < m ? md : 8224u + lane] = (uint8_t)va;
+        stg[lane + 64 < m ? md + 64 : 8224u + lane] = (uint8_t)vb;
+        if (m > 128) {
+          r = r2 + step; r = r >= per ? r - per : r;
+          for (uint32_t k0 = 128; k0 < m; k0 += 64) {
+            const uint32_t v = stg[ms + r];
+            stg[k0 + lane < m ? md + k0 : 8224u + lane] = (uint8_t)v;
+            r += step; r = r >= per ? r - per : r;
+          }
+        }
+      }
+    } else if (V == 8) {  // as 7, software pipelined: the reads of match j are issued, then match j + 1 is set up, then j is written
+      uint32_t B = rdlane(vB, 0), A = rdlane(vA, 0), C = rdlane(vC, 0);
+      for (uint32_t j = 0; j < nb; j++) {
+        const uint32_t m = B & 0xffffu, d = B >> 16;
+        const uint32_t ms = A & 0xffffu, md = (A >> 16) + lane;
+        const uint32_t per = d < m ? d : 0x40000000u;
+        const uint32_t step = d < m ? C >> 17 : 64u;
+        uint32_t r = lane - __umul24(__umul24(lane, C & 0x1ffffu) >> 16, d);
+        uint32_t r2 = r + step; r2 = r2 >= per ? r2 - per : r2;
+        const uint32_t va = stg[ms + r], vb = stg[ms + r2];
+        const uint32_t wa = lane < m ? md : 8224u + lane, wb = lane + 64 < m ? md + 64 : 8224u + lane;
+        const uint32_t jn = j + 1 < nb ? j + 1 : j;
+        B = rdlane(vB, jn); A = rdlane(vA, jn); C = rdlane(vC, jn);
+        stg[wa] = (uint8_t)va;
+        stg[wb] = (uint8_t)vb;
+        if (m > 128) {
+          r = r2 + step; r = r >= per ? r - per : r;
+          for (uint32_t k0 = 128; k0 < m; k0 += 64) {
+            const uint32_t v = stg[ms + r];
+            stg[k0 + lane < m ? md + k0 : 8224u + lane] = (uint8_t)v;
+            r += step; r = r >= per ? r - per : r;
+          }
+        }
+      }
     } else if (V == 3) {  // plain copies, dummy-address masking instead of exec masking
       for (uint32_t j = 0; j < nb; j++) {
         const uint32_t B = rdlane(vB, j);
@@ -196,5 +243,7 @@ int main(int argc, char **argv) {
   RUN(4, "full, 1 piece/step, dummy masking");
   RUN(5, "full, write-behind, dummy masking");
   RUN(6, "full, branch-free modulo, dummy masking");
+  RUN(7, "magic modulo, 2 pieces straight-line");
+  RUN(8, "magic modulo, 2 pieces, pipelined set-up");
   return 0;
 }
