@@ -180,6 +180,18 @@ int32_t lz4mi_compress_hc_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int64_t ma
  * prefix; the shared d_dict (last 65536 bytes used) is the pre-filled prefix. */
 int32_t lz4mi_decompress_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t strict);
 
+/* lz4mi_decompress_batch for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same results; the launch's queue words and its block order list
+ * live in a static device array of the library (4 MiB + 256 B per GPU, held until the process
+ * ends) instead of context buffers, so the call performs no hipMalloc/hipFree.
+ * At most LZ4MI_STATIC_MAX_BLOCKS blocks per call: more -> LZ4MI_UNSUPPORTED_HERE with the
+ * reason in lz4mi_last_backend_error(ctx), nothing launched.  All contexts on one GPU share
+ * that array: calls that overlap in time on the same GPU (two contexts, two streams) race on
+ * it; calls on one context's stream are ordered and safe. */
+#define LZ4MI_STATIC_MAX_BLOCKS (1u << 20)
+int32_t lz4mi_decompress_batch_static(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t strict);
+
 /* xxh32 of each block's source bytes (seed 0): block checksums
  * (lib/src/frame/lz4_frame_encoder.dart:242-257, lz4_frame_decoder.dart:257-266).
  * Only d_src/d_src_off/d_src_len/src_* /nblocks are read; d_hash receives nblocks words. */

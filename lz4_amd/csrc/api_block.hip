@@ -62,7 +62,18 @@ extern "C" size_t lz4mi_compress_bound(size_t n) { return bound(n); }
 
 enum { kCounterDecode = 0 /* three words */, kCounterEncode = 4, kCounterHc = 5, kCounterOrder = 8 /* two words */, kNumCounters = 16 };
 
-static std::string g_create_error;  // reason of the last failed lz4mi_ctx_create
+// reason of the last failed lz4mi_ctx_create on the calling thread
+static thread_local std::string g_create_error;
+
+// Device memory of lz4mi_decompress_batch_static: the decoder's queue words and its block order list, which
+// lz4mi_decompress_batch keeps in buffers the context allocates.  Every GPU the library runs on holds its own
+// copy of this array (4 MiB + 256 B) until the process ends.  `scratch` is a host-side stand-in for the symbol:
+// host code uses the per-device address that lz4mi_ctx_create looks up, never the name.  (No `used`
+// attribute: the compiler exports the symbol to the runtime because host code names it; with `used`
+// it stays local to the code object and the runtime cannot find it.)
+constexpr uint32_t kStaticMaxBlocks = LZ4MI_STATIC_MAX_BLOCKS;
+constexpr uint32_t kStaticHead = 64;  // words in front of the order list (queue heads)
+static __device__ __align__(256) uint32_t scratch[kStaticHead + kStaticMaxBlocks];
 
 static int32_t create_fail(lz4mi_ctx *c, hipError_t e, const char *what) {
   g_create_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -95,6 +106,11 @@ extern "C" int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **ou
   }
   if ((e = hipMalloc((void **)&c->d_counters, kNumCounters * sizeof(uint32_t))) != hipSuccess)
     return create_fail(c, e, "hipMalloc");
+  // this device's copy of the static scratch array (the context's device is current here)
+  void *sp = nullptr;
+  if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess || !sp)
+    return create_fail(c, e, "hipGetSymbolAddress(scratch)");
+  c->static_scratch = (uint32_t *)sp;
   uint32_t wpc = 16;  // resident encoder wavefronts per CU (one 256 KiB table each)
   if (const char *v = getenv("LZ4MI_ENC_WAVES_PER_CU")) {
     int n = atoi(v);
@@ -185,7 +201,9 @@ int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a_in, int64_t accelerat
   return LZ4MI_OK;
 }
 
-int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
+// counters: kNumCounters queue words; order: one word per block.  Both are device memory that nothing
+// else on the stream uses while the launch runs.
+static int32_t run_decompress_with(lz4mi_ctx *c, const BatchArgs &a_in, bool strict, uint32_t *counters, uint32_t *order) {
   if (a_in.nblocks == 0) return LZ4MI_OK;
   BatchArgs a = a_in;
   if (a.dict == nullptr) a.dict_len = 0;
@@ -193,16 +211,32 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a_in, bool strict) {
     a.dict += a.dict_len - 65536;
     a.dict_len = 65536;
   }
-  uint32_t *counter = c->d_counters + kCounterDecode;
-  uint32_t *order_cnt = c->d_counters + kCounterOrder;
+  uint32_t *counter = counters + kCounterDecode;
+  uint32_t *order_cnt = counters + kCounterOrder;
   // one fill for the decode word and the order words (the encoders' words in between are zeroed by
   // their own launches before use; everything runs on the context's one stream)
   static_assert(kCounterDecode == 0 && kCounterOrder + 2 <= kNumCounters, "counter layout");
-  LZ4MI_HIP(c, hipMemsetAsync(c->d_counters, 0, (kCounterOrder + 2) * sizeof(uint32_t), c->stream));
-  LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
-  launch_decode(a, strict, counter, order_cnt, c->order.as<uint32_t>(), (uint32_t)c->cu_count, c->stream);
+  LZ4MI_HIP(c, hipMemsetAsync(counters, 0, (kCounterOrder + 2) * sizeof(uint32_t), c->stream));
+  launch_decode(a, strict, counter, order_cnt, order, (uint32_t)c->cu_count, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
+}
+
+int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict) {
+  if (a.nblocks == 0) return LZ4MI_OK;
+  LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
+  return run_decompress_with(c, a, strict, c->d_counters, c->order.as<uint32_t>());
+}
+
+// Same launch, with the queue words and the order list in the static scratch array: no allocation.
+int32_t run_decompress_static(lz4mi_ctx *c, const BatchArgs &a, bool strict) {
+  static_assert(kNumCounters <= kStaticHead, "scratch layout");
+  if (a.nblocks > kStaticMaxBlocks) {
+    c->err = "lz4mi_decompress_batch_static: " + std::to_string(a.nblocks) + " blocks, the static scratch holds " +
+             std::to_string(kStaticMaxBlocks);
+    return LZ4MI_UNSUPPORTED_HERE;
+  }
+  return run_decompress_with(c, a, strict, c->static_scratch, c->static_scratch + kStaticHead);
 }
 
 static void to_args(const lz4mi_batch *b, BatchArgs &a) {
@@ -252,6 +286,14 @@ extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, in
   BatchArgs a;
   to_args(b, a);
   return run_decompress(c, a, strict != 0);
+}
+
+extern "C" int32_t lz4mi_decompress_batch_static(lz4mi_ctx *c, const lz4mi_batch *b, int32_t strict) {
+  if (!c || !b) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  BatchArgs a;
+  to_args(b, a);
+  return run_decompress_static(c, a, strict != 0);
 }
 
 extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_t *d_hash) {

@@ -47,6 +47,7 @@ struct lz4mi_ctx {
   std::string err;
 
   uint32_t *d_counters = nullptr;  // work-queue heads, one per launch kind
+  uint32_t *static_scratch = nullptr;  // this device's address of the library's static scratch array
 
   // fast/HC encoder hash tables: one 65536-entry slot per resident wavefront
   lz4mi::DevBuf tables, slot_gen, dict_table, dict_copy;
