@@ -239,11 +239,11 @@ int32_t lz4mi_frame_encode(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
                            const lz4mi_frame_options *o, const uint8_t *dict, size_t dict_len,
                            uint8_t *dst, size_t cap, size_t *out_len);
 
-/* Same, device-resident source and destination (independent or linked blocks).
- * first_block_index/emit_header/emit_trailer let N ranks each encode a
- * contiguous block range of one frame: rank r passes its shard, gets per-block
- * stored sizes in d_stored_sizes, and after the sizes have been exchanged
- * calls lz4mi_frame_assemble_shard with its absolute base offset. */
+/* Same, device-resident source, dictionary and destination (independent or linked blocks);
+ * cap >= lz4mi_frame_bound(n, o) or LZ4MI_DST_TOO_SMALL.  *out_len (host) = frame bytes.
+ * The call synchronises the context's stream once (it reads the frame size back).
+ * A contentSize that differs from n: the frame is produced, *out_len is set, and the call
+ * returns LZ4MI_FORMAT_CONTENT_SIZE_ARG, as lz4mi_frame_encode does (:269-271). */
 int32_t lz4mi_frame_encode_device(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
                                   const lz4mi_frame_options *o, const uint8_t *d_dict,
                                   uint32_t dict_len, uint8_t *d_dst, uint64_t cap,
@@ -253,17 +253,22 @@ int32_t lz4mi_frame_encode_device(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t
  * resident) and report each block's record size in the frame:
  * 4 + stored_len (+4 with block checksums), where stored_len follows the
  * compressed-iff-smaller rule (lib/src/frame/lz4_frame_encoder.dart:235).
- * The compressed payloads stay in the context's scratch until step 2. */
+ * The compressed payloads stay in the context's scratch until step 2, and stored blocks
+ * stay where they are in d_src: the caller keeps d_src alive and makes NO other call on this
+ * context between step 1 and step 2 (any other entry point reuses that scratch and
+ * invalidates the shard: step 2 then returns LZ4MI_RANGE). */
 int32_t lz4mi_frame_shard_compress(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
                                    const lz4mi_frame_options *o, const uint8_t *d_dict,
                                    uint32_t dict_len, uint32_t *d_record_sizes,
                                    uint32_t *nblocks_out);
 
 /* Step 2: after the record sizes of all ranks have been all-gathered and
- * prefix-summed by the caller, write this rank's block records contiguously
- * into d_dst (the rank's window of the frame), i.e. bytes
- * [shard_base, shard_base + sum(record sizes)) of the frame body.
- * d_record_offsets[b] = offset of block b's record relative to d_dst. */
+ * prefix-summed by the caller (the exchange is the caller's: RCCL all-gather from
+ * torch.distributed, MPI, or a host gather; the library links no collective library),
+ * write this rank's block records into d_dst (the rank's window of the frame).
+ * d_record_offsets[b] = offset of block b's record relative to d_dst.
+ * d_src, n and o must be step 1's (LZ4MI_RANGE otherwise); a record that would end behind
+ * cap fails the call with LZ4MI_DST_TOO_SMALL before anything is written. */
 int32_t lz4mi_frame_shard_write(lz4mi_ctx *ctx, const uint8_t *d_src, uint64_t n,
                                 const lz4mi_frame_options *o, const uint64_t *d_record_offsets,
                                 uint8_t *d_dst, uint64_t cap);
@@ -289,9 +294,12 @@ int32_t lz4mi_frame_decode_next(lz4mi_ctx *ctx, const uint8_t *src, size_t len, 
                                 int32_t have_prev_dict, int64_t max_out, uint8_t *dst, size_t cap,
                                 size_t *out_len, uint32_t *dict_id_needed);
 
-/* Size of the output lz4mi_frame_decode_next will need for the next frame:
- * parses only the header and walks the block size words on the host.
- * Returns an upper bound (blocks * blockMaxSize), or the contentSize field. */
+/* Capacity that lz4mi_frame_decode_next needs at most for the next frame: parses the header and
+ * walks the block size words on the host (no GPU work).  Sum over the block records of: the
+ * payload size for a stored block; min(blockMaxSize, 255 * payload size + 32) for a compressed
+ * one (a payload byte yields at most 255 output bytes).  The contentSize field is not trusted
+ * (a frame may lie; the reference reports that only after decoding, :317-321).  A caller with an
+ * output limit passes min(bound, limit + 1) as cap. */
 int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound);
 
 /* ---------------------------------------------------- host-only frame formats

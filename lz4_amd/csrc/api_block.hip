@@ -418,7 +418,9 @@ extern "C" int32_t lz4mi_block_decompress_into(lz4mi_ctx *c, const uint8_t *src,
   if (max_len - prefix_len > 0x7fffffff || n > 0x7fffffff || prefix_len > 0x7fffffff) return LZ4MI_UNSUPPORTED_HERE;
   OneResult r;
   size_t room = max_len - prefix_len;
-  int32_t st = one_block(c, src, n, dst, prefix_len, room, (uint32_t)room, 3, 0, &r);
+  // a match reaches back 65535 bytes at most: only the tail of a long prefix goes to the device
+  const size_t keep = prefix_len < 65536 ? prefix_len : 65536;
+  int32_t st = one_block(c, src, n, dst + (prefix_len - keep), keep, room, (uint32_t)room, 3, 0, &r);
   if (st) return st;
   if (r.out_len) LZ4MI_HIP(c, hipMemcpy(dst + prefix_len, c->out.p, r.out_len, hipMemcpyDeviceToHost));
   if (out_len) *out_len = prefix_len + r.out_len;

@@ -67,6 +67,11 @@ struct lz4mi_ctx {
   // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
   uint32_t shard_blocks = 0;
   int shard_block_checksum = 0;
+  // set by lz4mi_frame_shard_compress, cleared by every other entry point (they reuse the scratch)
+  bool shard_valid = false;
+  const uint8_t *shard_src = nullptr;
+  uint64_t shard_n = 0;
+  int shard_block_size_id = 0;
 
   void *h_pin = nullptr;  // pinned host scratch for small read-backs
   size_t h_pin_cap = 0;
@@ -82,6 +87,7 @@ inline int32_t fail(lz4mi_ctx *c, hipError_t e, const char *what) {
 // First HIP call of every entry point: makes the context's device current and drops an error code
 // left behind by the caller's own HIP calls (hipGetLastError after a launch would report it as ours).
 inline hipError_t enter_device(lz4mi_ctx *c) {
+  c->shard_valid = false;
   (void)hipGetLastError();
   return hipSetDevice(c->device);
 }

@@ -198,16 +198,46 @@ extern "C" int32_t lz4mi_frame_shard_compress(lz4mi_ctx *c, const uint8_t *d_src
   if (d_record_sizes && *nblocks_out)
     LZ4MI_HIP(c, hipMemcpyAsync(d_record_sizes, c->record_size.p, (size_t)*nblocks_out * 4,
                                 hipMemcpyDeviceToDevice, c->stream));
+  c->shard_valid = true;
+  c->shard_src = d_src;
+  c->shard_n = n;
+  c->shard_block_size_id = o->block_size_id;
   return LZ4MI_OK;
 }
 
 extern "C" int32_t lz4mi_frame_shard_write(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
                                            const lz4mi_frame_options *o, const uint64_t *d_record_offsets,
                                            uint8_t *d_dst, uint64_t cap) {
-  (void)d_src; (void)n; (void)o; (void)cap;
-  if (!c || !d_record_offsets || !d_dst) return LZ4MI_RANGE;
+  if (!c || !o || !d_record_offsets || !d_dst) return LZ4MI_RANGE;
+  // the records come out of the scratch step 1 left behind: refuse when anything ran in between, or
+  // when this is not step 1's shard
+  const bool valid = c->shard_valid && c->shard_src == d_src && c->shard_n == n &&
+                     c->shard_block_size_id == o->block_size_id &&
+                     (c->shard_block_checksum != 0) == (o->block_checksum != 0);
   LZ4MI_HIP(c, ::lz4mi::enter_device(c));
-  return shard_write(c, d_record_offsets, d_dst);
+  if (!valid) {
+    c->err = "lz4mi_frame_shard_write: no matching lz4mi_frame_shard_compress directly before this call";
+    return LZ4MI_RANGE;
+  }
+  const uint32_t nb = c->shard_blocks;
+  if (nb) {  // every record inside [0, cap) of the window, before anything is written
+    int32_t st = pin_reserve(c, 64);
+    if (st) return st;
+    LZ4MI_HIP(c, c->total.ensure(64));
+    uint32_t *flag = c->total.as<uint32_t>();
+    LZ4MI_HIP(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    launch_record_bounds(d_record_offsets, c->record_size.as<uint32_t>(), nb, cap, flag, c->stream);
+    LZ4MI_HIP(c, hipGetLastError());
+    LZ4MI_HIP(c, hipMemcpyAsync(c->h_pin, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+    if (*(uint32_t *)c->h_pin) {
+      c->shard_valid = true;  // nothing was touched: the caller may try again with a larger window
+      return LZ4MI_DST_TOO_SMALL;
+    }
+  }
+  int32_t st = shard_write(c, d_record_offsets, d_dst);
+  c->shard_valid = st == LZ4MI_OK;  // writing again (another window) is allowed
+  return st;
 }
 
 extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
@@ -234,6 +264,8 @@ extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src,
   launch_put_words(d_dst + body_end, c->words.as<uint32_t>(), o->content_checksum ? 1 : 0, true, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   if (out_len) *out_len = body_end + 4 + (o->content_checksum ? 4 : 0);
+  // raised after all the work, like the reference (:269-271): the frame is in d_dst, *out_len is set
+  if (o->has_content_size && n != o->content_size) return LZ4MI_FORMAT_CONTENT_SIZE_ARG;
   return LZ4MI_OK;
 }
 
@@ -260,7 +292,7 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   uint64_t total = 0;
   st = lz4mi_frame_encode_device(c, c->in.as<uint8_t>(), n, o, d_dict, (uint32_t)dict_len, c->out.as<uint8_t>(),
                                  fb, &total);
-  if (st) return st;
+  if (st && st != LZ4MI_FORMAT_CONTENT_SIZE_ARG) return st;
   if (total > cap) return LZ4MI_DST_TOO_SMALL;
   LZ4MI_HIP(c, hipMemcpyAsync(dst, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
   LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
@@ -308,9 +340,34 @@ int32_t parse_header(const uint8_t *p, size_t rem, Header *h) {
   return LZ4MI_OK;
 }
 
+// Most bytes a compressed block of `size` bytes can decode to: every input byte is at best a length
+// extension byte worth 255 output bytes (a token's 15 + 19 come with three bytes of input).
+static inline uint64_t decoded_bound(uint32_t size, size_t slot) {
+  const uint64_t m = 255ull * size + 32u;
+  return m < slot ? m : slot;
+}
+
+uint64_t planned_output(const Blk &k, size_t slot) { return k.raw ? k.size : decoded_bound(k.size, slot); }
+
+// Device bytes the block slots of one launch may take; more blocks go through further launches.
+static size_t decode_scratch_budget() {
+  size_t mb = 2048;
+  if (const char *e = getenv("LZ4MI_DECODE_SCRATCH_MB")) {  // read per call: tests shrink it to force several launches
+    long n = atol(e);
+    if (n >= 1 && n <= (1l << 20)) mb = (size_t)n;
+  }
+  return mb << 20;
+}
+
 // Decodes the collected blocks on the device and folds the per-block results in stream
 // order.  `region` = host bytes that contain every payload, uploaded once.
 // walk_err: structural error met while reading block blocks.size() (0 = none).
+//
+// Device memory follows the data, not blocks x blockMaxSize: a block's slot is what its payload can
+// decode to at most (decoded_bound), the slots of one launch stay within decode_scratch_budget() and
+// within what the output limits still allow plus one block, and a frame that takes several launches, or
+// whose blocks do not fill their slots, is compacted launch by launch into one buffer sized by those
+// same limits.
 int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, const std::vector<Blk> &blocks,
                       size_t slot, bool indep, const uint8_t *dict, size_t dict_len, bool have_dict,
                       int32_t walk_err, int64_t max_out, bool want_content_hash, bool legacy,
@@ -332,104 +389,69 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     return LZ4MI_OK;
   }
   LZ4MI_HIP(c, c->in.ensure(region_len + 16));
-  LZ4MI_HIP(c, c->out.ensure((size_t)nb * slot + 16));
   LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, region, region_len, hipMemcpyHostToDevice, c->stream));
   const uint8_t *d_dict = nullptr;
   if (have_dict && dict_len) {
+    if (dict_len > 65536) {  // the decoder keeps the last 65536 bytes (lz4_frame_decoder.dart:278-282)
+      dict += dict_len - 65536;
+      dict_len = 65536;
+    }
     LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
     LZ4MI_HIP(c, hipMemcpyAsync(c->dictbuf.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
     d_dict = c->dictbuf.as<uint8_t>();
   }
-  // per-block arrays: [payload_off u64][payload_len u32][raw u32][dst_off u64][out_len u32][status i32][hash u32]
-  const size_t hb = (size_t)nb * (8 + 4 + 4 + 8 + 4 + 4 + 4);
+  // what the caller's buffer and the output limit still allow; the block that crosses it may
+  // overshoot by one slot before the fold below reports it
+  uint64_t limit_total = cap;
+  if (max_out >= 0 && (uint64_t)max_out < limit_total) limit_total = (uint64_t)max_out;
+  uint64_t plan_total = 0;
+  for (uint32_t b = 0; b < nb; b++) plan_total += planned_output(blocks[b], slot);
+  const uint64_t final_cap = plan_total < limit_total + slot ? plan_total : limit_total + slot;
+
+  // per-block arrays, host (pinned) and device, same layout:
+  // fixed:    [payload_off u64][payload_len u32][raw u32][dec_len u32][cap u32]
+  // per launch: [dst_off u64][copy_src u64][copy_dst u64][copy_len u32]
+  // results:  [out_len u32][status i32][hash u32]
+  const size_t fixed_bytes = (size_t)nb * 24, hb = (size_t)nb * 64;
   int32_t st = pin_reserve(c, hb + 64);
   if (st) return st;
   uint64_t *h_poff = (uint64_t *)c->h_pin;
-  uint64_t *h_doff = h_poff + nb;
-  uint32_t *h_plen = (uint32_t *)(h_doff + nb);
+  uint32_t *h_plen = (uint32_t *)(h_poff + nb);
   uint32_t *h_raw = h_plen + nb;
-  uint32_t *h_olen = h_raw + nb;
+  uint32_t *h_dlen = h_raw + nb;
+  uint32_t *h_cap = h_dlen + nb;
+  uint64_t *h_doff = (uint64_t *)(h_cap + nb);
+  uint64_t *h_csrc = h_doff + nb;
+  uint64_t *h_cdst = h_csrc + nb;
+  uint32_t *h_clen = (uint32_t *)(h_cdst + nb);
+  uint32_t *h_olen = h_clen + nb;
   int32_t *h_stat = (int32_t *)(h_olen + nb);
   uint32_t *h_hash = (uint32_t *)(h_stat + nb);
   LZ4MI_HIP(c, c->aux.ensure(hb + 64));
   uint64_t *d_poff = c->aux.as<uint64_t>();
-  uint64_t *d_doff = d_poff + nb;
-  uint32_t *d_plen = (uint32_t *)(d_doff + nb);
+  uint32_t *d_plen = (uint32_t *)(d_poff + nb);
   uint32_t *d_raw = d_plen + nb;
-  uint32_t *d_olen = d_raw + nb;
+  uint32_t *d_dlen = d_raw + nb;
+  uint32_t *d_cap = d_dlen + nb;
+  uint64_t *d_doff = (uint64_t *)(d_cap + nb);
+  uint64_t *d_csrc = d_doff + nb;
+  uint64_t *d_cdst = d_csrc + nb;
+  uint32_t *d_clen = (uint32_t *)(d_cdst + nb);
+  uint32_t *d_olen = d_clen + nb;
   int32_t *d_stat = (int32_t *)(d_olen + nb);
   uint32_t *d_hash = (uint32_t *)(d_stat + nb);
 
   bool any_ck = false;
   for (uint32_t b = 0; b < nb; b++) {
     h_poff[b] = blocks[b].payload_off;
-    h_doff[b] = (uint64_t)b * slot;
     h_plen[b] = blocks[b].size;
     h_raw[b] = blocks[b].raw;
+    h_dlen[b] = (blocks[b].raw && indep) ? 0u : blocks[b].size;  // a stored block decodes to nothing: it is copied
+    h_cap[b] = (uint32_t)decoded_bound(blocks[b].size, slot);    // tmp ByteWriter(maxLength: blockMaxSize) :292
     any_ck |= blocks[b].has_ck != 0;
   }
-  LZ4MI_HIP(c, hipMemcpyAsync(d_poff, h_poff, (size_t)nb * (8 + 8 + 4 + 4), hipMemcpyHostToDevice, c->stream));
+  LZ4MI_HIP(c, hipMemcpyAsync(d_poff, h_poff, fixed_bytes, hipMemcpyHostToDevice, c->stream));
   LZ4MI_HIP(c, hipMemsetAsync(d_olen, 0, (size_t)nb * 8, c->stream));
-
-  if (indep) {
-    // compressed blocks through the batch decoder; stored blocks are plain copies.
-    // A stored block's src_len is zeroed for the decoder (decodes to nothing, status OK).
-    std::vector<uint64_t> raw_src, raw_dst;
-    std::vector<uint32_t> raw_len, dec_len(nb);
-    for (uint32_t b = 0; b < nb; b++) {
-      dec_len[b] = blocks[b].raw ? 0u : blocks[b].size;
-      if (blocks[b].raw) {
-        raw_src.push_back((uint64_t)(uintptr_t)(c->in.as<uint8_t>() + blocks[b].payload_off));
-        raw_dst.push_back((uint64_t)b * slot);
-        raw_len.push_back(blocks[b].size);
-      }
-    }
-    LZ4MI_HIP(c, c->payload_len.ensure((size_t)nb * 4));
-    LZ4MI_HIP(c, hipMemcpyAsync(c->payload_len.p, dec_len.data(), (size_t)nb * 4, hipMemcpyHostToDevice, c->stream));
-    BatchArgs a;
-    memset(&a, 0, sizeof a);
-    a.src = c->in.as<uint8_t>();
-    a.src_off = d_poff;
-    a.src_len = c->payload_len.as<uint32_t>();
-    a.dst = c->out.as<uint8_t>();
-    a.dst_off = d_doff;
-    a.dst_cap_uniform = (uint32_t)slot;  // tmp ByteWriter(maxLength: blockMaxSize) :292
-    a.dict = d_dict;
-    a.dict_len = (uint32_t)(d_dict ? dict_len : 0);
-    a.nblocks = nb;
-    a.out_len = d_olen;
-    a.status = d_stat;
-    st = run_decompress(c, a, false);
-    if (st) return st;
-    if (!raw_src.empty()) {
-      const size_t nr = raw_src.size();
-      LZ4MI_HIP(c, c->payload_addr.ensure(nr * 8));
-      LZ4MI_HIP(c, c->rec_off.ensure(nr * 8));
-      LZ4MI_HIP(c, c->record_size.ensure(nr * 4));
-      LZ4MI_HIP(c, hipMemcpyAsync(c->payload_addr.p, raw_src.data(), nr * 8, hipMemcpyHostToDevice, c->stream));
-      LZ4MI_HIP(c, hipMemcpyAsync(c->rec_off.p, raw_dst.data(), nr * 8, hipMemcpyHostToDevice, c->stream));
-      LZ4MI_HIP(c, hipMemcpyAsync(c->record_size.p, raw_len.data(), nr * 4, hipMemcpyHostToDevice, c->stream));
-      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope below
-      launch_seg_copy(c->payload_addr.as<uint64_t>(), c->out.as<uint8_t>(), c->rec_off.as<uint64_t>(), 0,
-                      c->record_size.as<uint32_t>(), (uint32_t)nr, c->stream);
-    } else {
-      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-    }
-  } else {
-    ChainArgs ch;
-    ch.src = c->in.as<uint8_t>();
-    ch.payload_off = d_poff;
-    ch.payload_len = d_plen;
-    ch.raw = d_raw;
-    ch.nblocks = nb;
-    ch.block_max = (uint32_t)slot;
-    ch.dst = c->out.as<uint8_t>();
-    ch.dict = d_dict;
-    ch.dict_len = (uint32_t)(d_dict ? dict_len : 0);
-    ch.out_len = d_olen;
-    ch.status = d_stat;
-    launch_decode_chain(ch, c->stream);
-  }
   if (any_ck) {  // block checksum of the payload as stored (:257-266)
     BatchArgs h;
     memset(&h, 0, sizeof h);
@@ -439,32 +461,144 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     h.nblocks = nb;
     launch_xxh32_batch(h, d_hash, c->stream);
   }
-  LZ4MI_HIP(c, hipGetLastError());
-  LZ4MI_HIP(c, hipMemcpyAsync(h_olen, d_olen, (size_t)nb * 12, hipMemcpyDeviceToHost, c->stream));
-  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
 
-  // fold in stream order: first failing block decides
   uint64_t produced = 0;
   int32_t err = LZ4MI_OK;
-  bool contiguous = true;
   uint32_t good = 0;
-  for (uint32_t b = 0; b < nb && !err; b++) {
+  const uint8_t *d_frame_out = nullptr;
+
+  // one block's results in stream order: the first failing block decides
+  auto fold = [&](uint32_t b) -> bool {
     const Blk &k = blocks[b];
-    if (k.has_ck && h_hash[b] != k.ck) { err = LZ4MI_CORRUPT_BLOCK_CK; break; }
-    uint32_t dsize = (k.raw && indep) ? k.size : h_olen[b];
-    if (!(k.raw && indep) && h_stat[b] != LZ4MI_OK) { err = h_stat[b]; break; }
-    if (!indep && !k.raw && dsize > slot) { err = LZ4MI_CORRUPT_BLOCK_SIZE; break; }  // :376-378
-    if (max_out >= 0 && produced + dsize > (uint64_t)max_out) { err = LZ4MI_LIMIT; break; }
-    if (produced + dsize > cap) { err = LZ4MI_DST_TOO_SMALL; break; }
-    if (indep && produced != (uint64_t)b * slot) contiguous = false;
+    if (k.has_ck && h_hash[b] != k.ck) { err = LZ4MI_CORRUPT_BLOCK_CK; return false; }
+    const uint32_t dsize = (k.raw && indep) ? k.size : h_olen[b];
+    if (!(k.raw && indep) && h_stat[b] != LZ4MI_OK) { err = h_stat[b]; return false; }
+    if (!indep && !k.raw && dsize > slot) { err = LZ4MI_CORRUPT_BLOCK_SIZE; return false; }  // :376-378
+    if (max_out >= 0 && produced + dsize > (uint64_t)max_out) { err = LZ4MI_LIMIT; return false; }
+    if (produced + dsize > cap) { err = LZ4MI_DST_TOO_SMALL; return false; }
     h_olen[b] = dsize;
     produced += dsize;
     good = b + 1;
     if (legacy && (b + 1 < nb || legacy_last_has_next) && dsize != slot) {  // :128-132
       err = LZ4MI_CORRUPT_LEGACY_NOT_FULL;
-      break;
+      return false;
     }
+    return true;
+  };
+
+  if (!indep) {
+    // linked blocks: one wavefront walks the chain over one contiguous output
+    LZ4MI_HIP(c, c->out.ensure((size_t)final_cap + 16));
+    ChainArgs ch;
+    ch.src = c->in.as<uint8_t>();
+    ch.payload_off = d_poff;
+    ch.payload_len = d_plen;
+    ch.raw = d_raw;
+    ch.nblocks = nb;
+    ch.block_max = (uint32_t)slot;
+    ch.dst = c->out.as<uint8_t>();
+    ch.dst_limit = limit_total;  // the buffer holds one more slot than this
+    ch.dict = d_dict;
+    ch.dict_len = (uint32_t)(d_dict ? dict_len : 0);
+    ch.out_len = d_olen;
+    ch.status = d_stat;
+    launch_decode_chain(ch, c->stream);
+    LZ4MI_HIP(c, hipGetLastError());
+    LZ4MI_HIP(c, hipMemcpyAsync(h_olen, d_olen, (size_t)nb * 12, hipMemcpyDeviceToHost, c->stream));
+    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t b = 0; b < nb; b++)
+      if (!fold(b)) break;
+    d_frame_out = c->out.as<uint8_t>();
+  } else {
+    const size_t budget = decode_scratch_budget();
+    bool gathered = false;  // earlier launches' output sits in c->comp
+    uint32_t b0 = 0;
+    while (b0 < nb && !err) {
+      // ---- the blocks of this launch, their slots packed at 16-byte steps
+      const uint64_t left = limit_total > produced ? limit_total - produced : 0;
+      const uint64_t room = left + slot < budget ? left + slot : budget;
+      uint64_t run = 0;
+      uint32_t b1 = b0, nraw = 0;
+      while (b1 < nb) {
+        const uint64_t need = round_up((size_t)planned_output(blocks[b1], slot), 16);
+        if (b1 > b0 && run + need > room) break;
+        h_doff[b1] = run;
+        if (blocks[b1].raw) {  // stored blocks are plain copies into their slots
+          h_csrc[nraw] = (uint64_t)(uintptr_t)(c->in.as<uint8_t>() + blocks[b1].payload_off);
+          h_cdst[nraw] = run;
+          h_clen[nraw] = blocks[b1].size;
+          nraw++;
+        }
+        run += need;
+        b1++;
+      }
+      const uint32_t n = b1 - b0;
+      LZ4MI_HIP(c, c->out.ensure((size_t)run + 16));
+      uint8_t *d_slots = c->out.as<uint8_t>();
+      LZ4MI_HIP(c, hipMemcpyAsync(d_doff + b0, h_doff + b0, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+      BatchArgs a;
+      memset(&a, 0, sizeof a);
+      a.src = c->in.as<uint8_t>();
+      a.src_off = d_poff + b0;
+      a.src_len = d_dlen + b0;
+      a.dst = d_slots;
+      a.dst_off = d_doff + b0;
+      a.dst_cap = d_cap + b0;
+      a.dict = d_dict;
+      a.dict_len = (uint32_t)(d_dict ? dict_len : 0);
+      a.nblocks = n;
+      a.out_len = d_olen + b0;
+      a.status = d_stat + b0;
+      st = run_decompress(c, a, false);
+      if (st) return st;
+      if (nraw) {
+        LZ4MI_HIP(c, hipMemcpyAsync(d_csrc, h_csrc, (size_t)nraw * 8, hipMemcpyHostToDevice, c->stream));
+        LZ4MI_HIP(c, hipMemcpyAsync(d_cdst, h_cdst, (size_t)nraw * 8, hipMemcpyHostToDevice, c->stream));
+        LZ4MI_HIP(c, hipMemcpyAsync(d_clen, h_clen, (size_t)nraw * 4, hipMemcpyHostToDevice, c->stream));
+        launch_seg_copy(d_csrc, d_slots, d_cdst, 0, d_clen, nraw, c->stream);
+      }
+      LZ4MI_HIP(c, hipGetLastError());
+      LZ4MI_HIP(c, hipMemcpyAsync(h_olen + b0, d_olen + b0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+      LZ4MI_HIP(c, hipMemcpyAsync(h_stat + b0, d_stat + b0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+      if (any_ck) LZ4MI_HIP(c, hipMemcpyAsync(h_hash + b0, d_hash + b0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+
+      // ---- fold, and see whether the good blocks already lie back to back in their slots
+      const uint64_t before = produced;
+      bool packed = true;
+      uint32_t g1 = b0;
+      for (uint32_t b = b0; b < b1; b++) {
+        if (produced - before != h_doff[b]) packed = false;
+        const bool ok = fold(b);
+        if (good == b + 1) g1 = b + 1;
+        if (!ok) break;
+      }
+      if (b0 == 0 && !gathered && packed && (b1 == nb || err)) {
+        d_frame_out = d_slots;  // the whole output, in place
+      } else if (g1 > b0) {
+        if (!gathered) {
+          LZ4MI_HIP(c, c->comp.ensure((size_t)final_cap + 16));
+          gathered = true;
+        }
+        for (uint32_t b = b0; b < g1; b++) {
+          h_csrc[b - b0] = (uint64_t)(uintptr_t)(d_slots + h_doff[b]);
+          h_cdst[b - b0] = b == b0 ? before : h_cdst[b - b0 - 1] + h_olen[b - 1];
+          h_clen[b - b0] = h_olen[b];
+        }
+        const uint32_t m = g1 - b0;
+        LZ4MI_HIP(c, hipMemcpyAsync(d_csrc, h_csrc, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        LZ4MI_HIP(c, hipMemcpyAsync(d_cdst, h_cdst, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+        LZ4MI_HIP(c, hipMemcpyAsync(d_clen, h_clen, (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        launch_seg_copy(d_csrc, c->comp.as<uint8_t>(), d_cdst, 0, d_clen, m, c->stream);
+        LZ4MI_HIP(c, hipGetLastError());
+        LZ4MI_HIP(c, hipStreamSynchronize(c->stream));  // the lists and the slots are reused by the next launch
+        d_frame_out = c->comp.as<uint8_t>();
+      }
+      b0 = b1;
+    }
+    if (!d_frame_out) d_frame_out = c->out.as<uint8_t>();
   }
+
   if (!err && walk_err) err = walk_err;
   if (err && extras && extras->partial) {  // deliver the blocks in front of the failing one
     extras->deferred = err;
@@ -474,29 +608,6 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   if (extras) {
     extras->good_blocks = good;
     extras->sizes.assign(h_olen, h_olen + good);
-  }
-
-  // gather the output
-  const uint8_t *d_frame_out = c->out.as<uint8_t>();
-  if (!contiguous) {  // short non-final blocks: compact the slots on the device
-    LZ4MI_HIP(c, c->comp.ensure((size_t)produced + 16));
-    std::vector<uint64_t> s_addr(good), d_off(good);
-    uint64_t run = 0;
-    for (uint32_t b = 0; b < good; b++) {
-      s_addr[b] = (uint64_t)(uintptr_t)(c->out.as<uint8_t>() + (uint64_t)b * slot);
-      d_off[b] = run;
-      run += h_olen[b];
-    }
-    LZ4MI_HIP(c, c->payload_addr.ensure((size_t)good * 8));
-    LZ4MI_HIP(c, c->rec_off.ensure((size_t)good * 8));
-    LZ4MI_HIP(c, c->record_size.ensure((size_t)good * 4));
-    LZ4MI_HIP(c, hipMemcpyAsync(c->payload_addr.p, s_addr.data(), (size_t)good * 8, hipMemcpyHostToDevice, c->stream));
-    LZ4MI_HIP(c, hipMemcpyAsync(c->rec_off.p, d_off.data(), (size_t)good * 8, hipMemcpyHostToDevice, c->stream));
-    LZ4MI_HIP(c, hipMemcpyAsync(c->record_size.p, h_olen, (size_t)good * 4, hipMemcpyHostToDevice, c->stream));
-    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-    launch_seg_copy(c->payload_addr.as<uint64_t>(), c->comp.as<uint8_t>(), c->rec_off.as<uint64_t>(), 0,
-                    c->record_size.as<uint32_t>(), good, c->stream);
-    d_frame_out = c->comp.as<uint8_t>();
   }
   if (want_content_hash) {  // xxh32(frameOut) :306-315
     LZ4MI_HIP(c, c->words.ensure(64));
@@ -641,7 +752,7 @@ extern "C" int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size
   } else if (magic != kLegacyMagic) {
     return LZ4MI_OK;
   }
-  size_t nb = 0;
+  uint64_t total = 0;
   while (len - off >= 4) {
     uint32_t raw = rd32(src + off);
     if (magic == kLegacyMagic &&
@@ -649,12 +760,13 @@ extern "C" int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size
       break;
     off += 4;
     if (raw == 0) break;
-    uint32_t size = raw & 0x7FFFFFFFu;
+    uint32_t size = magic == kLegacyMagic ? raw : raw & 0x7FFFFFFFu;
     if (size > len - off) break;
     off += size + (ck ? 4 : 0);
     if (off > len) break;
-    nb++;
+    Blk k = {0, size, magic == kLegacyMagic ? 0u : (raw >> 31) & 1u, 0, 0};
+    total += planned_output(k, bmax);
   }
-  *bound_out = nb * bmax;
+  *bound_out = (size_t)total;
   return LZ4MI_OK;
 }

@@ -896,6 +896,7 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
   uint64_t start = 0;
   uint32_t b = 0;
   for (; b < c.nblocks; b++) {
+    if (start > c.dst_limit) break;  // the caller's output limit is already crossed: the host reports it
     const uint8_t *payload = c.src + c.payload_off[b];
     const uint32_t len = c.payload_len[b];
     uint32_t produced = 0;

@@ -54,6 +54,8 @@ struct Header {
 };
 
 int32_t parse_header(const uint8_t *p, size_t rem, Header *h);
+// Most bytes block k can add to the output (slot = the frame's blockMaxSize).
+uint64_t planned_output(const Blk &k, size_t slot);
 
 // Optional extras of decode_blocks for callers that deliver output block by block.
 struct DecodeExtras {

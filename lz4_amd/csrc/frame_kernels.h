@@ -28,6 +28,8 @@ void launch_frame_words(uint8_t *frame, const uint64_t *rec_off, const uint32_t 
                         const uint32_t *payload_len, const uint32_t *hashes, uint32_t nblocks, hipStream_t s);
 void launch_seg_copy(const uint64_t *src_addr, uint8_t *dst_base, const uint64_t *dst_off, uint64_t dst_delta,
                      const uint32_t *len, uint32_t nseg, hipStream_t s);
+void launch_record_bounds(const uint64_t *rec_off, const uint32_t *record_size, uint32_t nblocks, uint64_t cap,
+                          uint32_t *flag, hipStream_t s);
 void launch_put_words(uint8_t *dst, const uint32_t *words, uint32_t nwords, bool end_mark, hipStream_t s);
 
 }  // namespace lz4mi

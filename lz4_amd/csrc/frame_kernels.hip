@@ -85,6 +85,15 @@ __global__ __launch_bounds__(256) void seg_copy_kernel(const uint64_t *src_addr,
   }
 }
 
+// flag[0] = 1 when a record would end behind `cap` (offsets are relative to the window).
+__global__ void record_bounds_kernel(const uint64_t *rec_off, const uint32_t *record_size, uint32_t nblocks,
+                                     uint64_t cap, uint32_t *flag) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const uint64_t o = rec_off[b];
+  if (o > cap || cap - o < record_size[b]) flag[0] = 1u;
+}
+
 __global__ void put_words_kernel(uint8_t *dst, const uint32_t *words, uint32_t nwords, uint32_t literal0,
                                  int use_literal0) {
   // trailer: end mark (literal 0) followed by device-computed words
@@ -113,6 +122,12 @@ void launch_seg_copy(const uint64_t *src_addr, uint8_t *dst_base, const uint64_t
   uint32_t grid = nseg < 65536u ? nseg : 65536u;
   hipLaunchKernelGGL(seg_copy_kernel, dim3(grid), dim3(256), 0, s, src_addr, dst_base, dst_off, dst_delta, len,
                      nseg);
+}
+void launch_record_bounds(const uint64_t *rec_off, const uint32_t *record_size, uint32_t nblocks, uint64_t cap,
+                          uint32_t *flag, hipStream_t s) {
+  if (!nblocks) return;
+  hipLaunchKernelGGL(record_bounds_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, rec_off, record_size,
+                     nblocks, cap, flag);
 }
 void launch_put_words(uint8_t *dst, const uint32_t *words, uint32_t nwords, bool end_mark, hipStream_t s) {
   hipLaunchKernelGGL(put_words_kernel, dim3(1), dim3(64), 0, s, dst, words, nwords, 0u, end_mark ? 1 : 0);

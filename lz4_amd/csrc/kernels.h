@@ -60,6 +60,7 @@ struct ChainArgs {
   uint32_t nblocks;
   uint32_t block_max;
   uint8_t *dst;                 // contiguous frame output
+  uint64_t dst_limit;           // no block starts behind this offset (the buffer holds block_max more)
   const uint8_t *dict;
   uint32_t dict_len;
   uint32_t *out_len;

@@ -111,7 +111,8 @@ def test_frame_decode_bound_walks_blocks():
     b = C.c_size_t(0)
     buf = C.create_string_buffer(frame, len(frame))
     assert L.lz4mi_frame_decode_bound(buf, len(frame), C.byref(b)) == 0
-    assert b.value == 2 * 65536
+    # two compressed blocks of 299 and 66 payload bytes: min(blockMaxSize, 255 * payload + 32) each
+    assert b.value == 65536 + (255 * 66 + 32)
 
 
 def test_options_validation_mirrors_reference():
