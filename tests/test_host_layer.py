@@ -224,3 +224,53 @@ def test_xxh32_state_digest_of_short_inputs_needs_no_gpu(oracle):
         for k in range(len(data)):  # one byte at a time: the carry path only
             assert L.lz4mi_xxh32_state_update(None, C.byref(s), data[k:k + 1], 1) == 0
         assert L.lz4mi_xxh32_state_digest(C.byref(s)) == oracle.xxh32(data)
+
+
+def _split_args(text):
+    """Top-level comma split of an argument list."""
+    args, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "(<":
+            depth += 1
+        elif ch in ")>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return [a for a in args if a and a != "void"]
+
+
+def test_dart_shim_binds_declared_symbols_with_matching_arity():
+    """The dart:ffi shim cannot be compiled here (no Dart SDK): hold it to the header mechanically.
+    Every symbol it looks up is declared in include/lz4mi.h with the same number of parameters."""
+    header = open(os.path.join(ROOT, "include", "lz4mi.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decl = {m.group(1): len(_split_args(m.group(2)))
+            for m in re.finditer(r"\b(lz4mi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)}
+    dart = open(os.path.join(ROOT, "lz4_amd", "dart", "dart_lz4_ffi.dart")).read()
+    typedefs = {m.group(1): m.group(2) for m in
+                re.finditer(r"typedef\s+(\w+)\s*=\s*[\w<>]+\s+Function\((.*?)\);", dart, flags=re.S)}
+    seen = 0
+    for m in re.finditer(r">\(\s*'(lz4mi_\w+)'\s*\)", dart):
+        name = m.group(1)
+        sigs = dart[dart.rindex("lookupFunction<", 0, m.start()) + len("lookupFunction<"):m.start()]
+        assert name in decl, f"{name} is not declared in lz4mi.h"
+        first = sigs.strip()
+        fm = re.match(r"[\w<>]+\s+Function\(", first)
+        if fm:  # inline native signature: take its balanced argument list
+            depth, k = 1, fm.end()
+            while depth:
+                depth += {"(": 1, ")": -1}.get(first[k], 0)
+                k += 1
+            nargs = len(_split_args(first[fm.end():k - 1]))
+        else:
+            alias = re.match(r"(\w+)", first).group(1)
+            assert alias in typedefs, alias
+            nargs = len(_split_args(typedefs[alias]))
+        assert nargs == decl[name], (name, nargs, decl[name])
+        seen += 1
+    assert seen >= 25
