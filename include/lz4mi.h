@@ -302,11 +302,58 @@ int32_t lz4mi_frame_decode_next(lz4mi_ctx *ctx, const uint8_t *src, size_t len, 
  * output limit passes min(bound, limit + 1) as cap. */
 int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound);
 
+/* ------------------------------------------------- sharded decode of one frame
+ * The frame decoder's block loop (lib/src/frame/lz4_frame_decoder.dart:238-304) split by
+ * contiguous block ranges over several GPUs.  lz4mi_frame_info is declared below.
+ *
+ * Step 1 (host, no GPU work): the walk over the size words (:243-255, structure only) of the
+ * standard frame at src.  record_off[k] = offset in src of record k's size word; at most
+ * max_records are stored (*nrecords is always the real count; more than max_records ->
+ * LZ4MI_DST_TOO_SMALL; record_off == NULL just counts).  *end_off = offset behind the end
+ * mark and content checksum.  Structural failures are the reference's: LZ4MI_FORMAT_EOF,
+ * LZ4MI_CORRUPT_BLOCK_SIZE, header errors. */
+struct lz4mi_frame_info_s;
+int32_t lz4mi_frame_block_table(const uint8_t *src, size_t len, struct lz4mi_frame_info_s *info,
+                                uint64_t *record_off, size_t max_records, size_t *nrecords,
+                                size_t *end_off);
+
+/* Step 2 (device): one rank decodes its records.  d_records[0..records_len) holds them (the
+ * rank's window of the frame), d_record_off[b] is record b's offset in that window.  Block b's
+ * bytes go to d_dst + b * blockMaxSize; d_out_len[b] / d_status[b] report what :251-296 would:
+ * size word over blockMaxSize -> LZ4MI_CORRUPT_BLOCK_SIZE, record cut short ->
+ * LZ4MI_FORMAT_EOF, block checksum (o->block_checksum) -> LZ4MI_CORRUPT_BLOCK_CK, then the
+ * block decoder's status with the temporary writer's blockMaxSize cap (LZ4MI_LIMIT).  The
+ * first failing block in frame order is the error the reference throws; the caller reduces
+ * over ranks.  Only o->block_size_id, block_checksum and block_independence (must be 1) are
+ * read.  Enqueued on the context's stream, not synchronised. */
+int32_t lz4mi_frame_shard_decode(lz4mi_ctx *ctx, const uint8_t *d_records, uint64_t records_len,
+                                 const uint64_t *d_record_off, uint32_t nblocks,
+                                 const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                 uint32_t dict_len, uint8_t *d_dst, uint32_t *d_out_len,
+                                 int32_t *d_status);
+
+/* Step 3 (device): the reference appends whatever each block yields (:291-296); blocks that do
+ * not fill their slot are packed here.  Copies d_len[b] bytes from d_slots + b * slot_stride to
+ * d_dst + d_dst_off[b] (offsets from the all-gathered decoded sizes, prefix-summed by the
+ * caller).  A block that would end behind cap fails the call with LZ4MI_DST_TOO_SMALL before
+ * anything is written (one stream synchronisation). */
+int32_t lz4mi_blocks_gather(lz4mi_ctx *ctx, const uint8_t *d_slots, uint64_t slot_stride,
+                            const uint32_t *d_len, const uint64_t *d_dst_off, uint32_t nblocks,
+                            uint8_t *d_dst, uint64_t cap);
+
+/* d_flags[b] = 1 when compressed block b (d_src / d_src_off / d_src_len / src_stride of the
+ * batch) breaks the LZ4 block format's end-of-block rules (last five bytes literals, last
+ * match starts at least twelve bytes before the end), 0 otherwise.  The reference's encoders
+ * produce such blocks (lib/src/block/lz4_block_encoder.dart:95,118: the search runs to the last
+ * four bytes and matches extend to the last byte) and its own decoder accepts them; liblz4
+ * and the lz4 CLI do not.  This reports how many, it changes nothing. */
+int32_t lz4mi_blocks_conformance(lz4mi_ctx *ctx, const lz4mi_batch *b, uint32_t *d_flags);
+
 /* ---------------------------------------------------- host-only frame formats
  * lz4FrameInfo  lib/src/frame/lz4_frame_info.dart:89-199: magic + descriptor only, no
  * payload is touched (no GPU work).  Fields mirror Lz4FrameInfo (:13-63); the has_* flags
  * stand for Dart's nullable fields. */
-typedef struct {
+typedef struct lz4mi_frame_info_s {
   uint32_t magic;
   int32_t is_skippable;
   int32_t is_legacy;

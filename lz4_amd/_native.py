@@ -81,6 +81,7 @@ EXPORTS = [
     "lz4mi_frame_encoder_update", "lz4mi_frame_encoder_finish", "lz4mi_frame_encoder_destroy",
     "lz4mi_frame_decoder_create", "lz4mi_frame_decoder_feed", "lz4mi_frame_decoder_next",
     "lz4mi_frame_decoder_set_dictionary", "lz4mi_frame_decoder_finish", "lz4mi_frame_decoder_destroy",
+    "lz4mi_frame_block_table", "lz4mi_frame_shard_decode", "lz4mi_blocks_gather", "lz4mi_blocks_conformance",
 ]
 
 _lib = None
@@ -142,6 +143,10 @@ def load():
         L.lz4mi_frame_decode_next.argtypes = [vp, vp, sz, psz, u8p, sz, i32, i32, i64, vp, sz, psz,
                                               C.POINTER(u32)]
         L.lz4mi_frame_decode_bound.argtypes = [vp, sz, psz]
+        L.lz4mi_frame_block_table.argtypes = [vp, sz, C.POINTER(FrameInfo), vp, sz, psz, psz]
+        L.lz4mi_frame_shard_decode.argtypes = [vp, vp, u64, vp, u32, C.POINTER(FrameOptions), vp, u32, vp, vp, vp]
+        L.lz4mi_blocks_gather.argtypes = [vp, vp, u64, vp, vp, u32, vp, u64]
+        L.lz4mi_blocks_conformance.argtypes = [vp, C.POINTER(Batch), vp]
         L.lz4mi_xxh32_state_init.argtypes = [C.POINTER(XxhState), u32]
         L.lz4mi_xxh32_state_init.restype = None
         L.lz4mi_xxh32_state_update.argtypes = [vp, C.POINTER(XxhState), u8p, sz]

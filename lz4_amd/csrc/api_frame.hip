@@ -734,6 +734,159 @@ extern "C" int32_t lz4mi_frame_decode_next(lz4mi_ctx *c, const uint8_t *src, siz
   return LZ4MI_OK;
 }
 
+// ------------------------------------------------- sharded decode (device resident)
+
+extern "C" int32_t lz4mi_frame_block_table(const uint8_t *src, size_t len, lz4mi_frame_info *info,
+                                           uint64_t *record_off, size_t max_records, size_t *nrecords,
+                                           size_t *end_off) {
+  if (!src || !nrecords) return LZ4MI_RANGE;
+  *nrecords = 0;
+  if (end_off) *end_off = 0;
+  if (len < 4) return LZ4MI_FORMAT_EOF;
+  if (rd32(src) != kFrameMagic) return LZ4MI_FORMAT_MAGIC;
+  Header h;
+  int32_t st = parse_header(src + 4, len - 4, &h);
+  if (st) return st;
+  if (info) {
+    memset(info, 0, sizeof *info);
+    info->magic = kFrameMagic;
+    info->block_independence = h.indep;
+    info->block_checksum = h.block_ck;
+    info->content_checksum = h.content_ck;
+    info->has_content_size = h.has_size;
+    info->has_dict_id = h.has_dict;
+    info->dict_id = h.dict_id;
+    info->block_max_size = (uint32_t)h.bmax;
+    info->header_size = (uint32_t)(4 + h.len);
+    info->content_size = h.content_size;
+  }
+  size_t off = 4 + h.len, n = 0;
+  for (;;) {  // lz4_frame_decoder.dart:243-255, structure only
+    if (len - off < 4) return LZ4MI_FORMAT_EOF;
+    const uint32_t word = rd32(src + off);
+    if (word == 0) { off += 4; break; }
+    const uint32_t size = word & 0x7FFFFFFFu;
+    if (size > h.bmax) return LZ4MI_CORRUPT_BLOCK_SIZE;
+    const size_t rec = 4 + (size_t)size + (h.block_ck ? 4 : 0);
+    if (rec > len - off) return LZ4MI_FORMAT_EOF;
+    if (record_off && n < max_records) record_off[n] = off;
+    n++;
+    off += rec;
+  }
+  if (h.content_ck) {
+    if (len - off < 4) return LZ4MI_FORMAT_EOF;
+    off += 4;
+  }
+  *nrecords = n;
+  if (end_off) *end_off = off;
+  return record_off && n > max_records ? LZ4MI_DST_TOO_SMALL : LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_frame_shard_decode(lz4mi_ctx *c, const uint8_t *d_records, uint64_t records_len,
+                                            const uint64_t *d_record_off, uint32_t nblocks,
+                                            const lz4mi_frame_options *o, const uint8_t *d_dict, uint32_t dict_len,
+                                            uint8_t *d_dst, uint32_t *d_out_len, int32_t *d_status) {
+  if (!c || !o || !d_out_len || !d_status) return LZ4MI_RANGE;
+  const size_t bmax = block_max_bytes(o->block_size_id);
+  if (!bmax) return LZ4MI_RANGE;
+  if (!o->block_independence) return LZ4MI_UNSUPPORTED_HERE;  // a linked frame is one serial chain
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  if (nblocks == 0) return LZ4MI_OK;
+  if (!d_records || !d_record_off || !d_dst) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, c->payload_addr.ensure((size_t)nblocks * 8));
+  LZ4MI_HIP(c, c->payload_len.ensure((size_t)nblocks * 4));
+  LZ4MI_HIP(c, c->comp_len.ensure((size_t)nblocks * 4));
+  LZ4MI_HIP(c, c->record_size.ensure((size_t)nblocks * 4));
+  LZ4MI_HIP(c, c->rec_off.ensure((size_t)nblocks * 8));
+  LZ4MI_HIP(c, c->stored_word.ensure((size_t)nblocks * 4));
+  LZ4MI_HIP(c, c->status.ensure((size_t)nblocks * 4));
+  LZ4MI_HIP(c, c->hashes.ensure((size_t)nblocks * 4));
+  RecordReadArgs r;
+  r.records = d_records;
+  r.records_len = records_len;
+  r.rec_off = d_record_off;
+  r.nblocks = nblocks;
+  r.block_max = (uint32_t)bmax;
+  r.block_checksum = o->block_checksum;
+  r.payload_addr = c->payload_addr.as<uint64_t>();
+  r.payload_len = c->payload_len.as<uint32_t>();
+  r.dec_len = c->comp_len.as<uint32_t>();
+  r.raw_len = c->record_size.as<uint32_t>();
+  r.slot_off = c->rec_off.as<uint64_t>();
+  r.expect = c->stored_word.as<uint32_t>();
+  r.pre_status = c->status.as<int32_t>();
+  launch_record_read(r, c->stream);
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = nullptr;  // absolute addresses
+  a.src_off = r.payload_addr;
+  a.src_len = r.dec_len;
+  a.dst = d_dst;
+  a.dst_stride = bmax;
+  a.dst_cap_uniform = (uint32_t)bmax;  // tmp ByteWriter(maxLength: blockMaxSize) lz4_frame_decoder.dart:292
+  a.dict = d_dict;
+  a.dict_len = d_dict ? dict_len : 0;
+  a.nblocks = nblocks;
+  a.out_len = d_out_len;
+  a.status = d_status;
+  int32_t st = run_decompress(c, a, false);
+  if (st) return st;
+  launch_seg_copy(r.payload_addr, d_dst, r.slot_off, 0, r.raw_len, nblocks, c->stream);  // stored blocks (:268-271)
+  if (o->block_checksum) {
+    BatchArgs h;
+    memset(&h, 0, sizeof h);
+    h.src = nullptr;
+    h.src_off = r.payload_addr;
+    h.src_len = r.payload_len;
+    h.nblocks = nblocks;
+    launch_xxh32_batch(h, c->hashes.as<uint32_t>(), c->stream);
+  }
+  launch_record_finish(r, c->hashes.as<uint32_t>(), d_out_len, d_status, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_blocks_gather(lz4mi_ctx *c, const uint8_t *d_slots, uint64_t slot_stride,
+                                       const uint32_t *d_len, const uint64_t *d_dst_off, uint32_t nblocks,
+                                       uint8_t *d_dst, uint64_t cap) {
+  if (!c) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  if (nblocks == 0) return LZ4MI_OK;
+  if (!d_slots || !d_len || !d_dst_off || !d_dst) return LZ4MI_RANGE;
+  int32_t st = pin_reserve(c, 64);
+  if (st) return st;
+  LZ4MI_HIP(c, c->total.ensure(64));
+  LZ4MI_HIP(c, c->payload_addr.ensure((size_t)nblocks * 8));
+  uint32_t *flag = c->total.as<uint32_t>();
+  LZ4MI_HIP(c, hipMemsetAsync(flag, 0, 4, c->stream));
+  launch_record_bounds(d_dst_off, d_len, nblocks, cap, flag, c->stream);
+  LZ4MI_HIP(c, hipMemcpyAsync(c->h_pin, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  launch_slot_addr(d_slots, slot_stride, nblocks, c->payload_addr.as<uint64_t>(), c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  if (*(uint32_t *)c->h_pin) return LZ4MI_DST_TOO_SMALL;  // nothing written
+  launch_seg_copy(c->payload_addr.as<uint64_t>(), d_dst, d_dst_off, 0, d_len, nblocks, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
+extern "C" int32_t lz4mi_blocks_conformance(lz4mi_ctx *c, const lz4mi_batch *b, uint32_t *d_flags) {
+  if (!c || !b || !d_flags) return LZ4MI_RANGE;
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  BatchArgs a;
+  memset(&a, 0, sizeof a);
+  a.src = b->d_src;
+  a.src_off = b->d_src_off;
+  a.src_len = b->d_src_len;
+  a.src_stride = b->src_stride;
+  a.src_len_uniform = b->src_len_uniform;
+  a.src_total = b->src_total;
+  a.nblocks = b->nblocks;
+  launch_block_conformance(a, d_flags, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  return LZ4MI_OK;
+}
+
 extern "C" int32_t lz4mi_frame_decode_bound(const uint8_t *src, size_t len, size_t *bound_out) {
   if (!bound_out) return LZ4MI_RANGE;
   *bound_out = 0;

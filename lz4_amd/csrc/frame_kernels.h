@@ -21,6 +21,28 @@ struct FramePlanArgs {
   uint32_t *record_size;    // out: 4 + payload (+4)
 };
 
+struct RecordReadArgs {
+  const uint8_t *records;    // this rank's window of the frame (device)
+  uint64_t records_len;
+  const uint64_t *rec_off;   // per block: offset of its size word in `records`
+  uint32_t nblocks;
+  uint32_t block_max;
+  int block_checksum;
+  uint64_t *payload_addr;    // out: device address of the stored payload
+  uint32_t *payload_len;     // out: stored payload length (0 when the record failed a check)
+  uint32_t *dec_len;         // out: payload length for the decoder (0 for stored blocks)
+  uint32_t *raw_len;         // out: bytes to copy for stored blocks
+  uint64_t *slot_off;        // out: b * block_max
+  uint32_t *expect;          // out: checksum word behind the payload
+  int32_t *pre_status;       // out: failure met before decoding, or OK
+};
+
+struct BatchArgs;
+void launch_record_read(const RecordReadArgs &r, hipStream_t s);
+void launch_record_finish(const RecordReadArgs &r, const uint32_t *hashes, uint32_t *out_len, int32_t *status,
+                          hipStream_t s);
+void launch_slot_addr(const uint8_t *slots, uint64_t stride, uint32_t nblocks, uint64_t *addr, hipStream_t s);
+void launch_block_conformance(const BatchArgs &a, uint32_t *flags, hipStream_t s);
 void launch_frame_plan(const FramePlanArgs &p, hipStream_t s);
 void launch_scan_sizes(const uint32_t *sizes, uint32_t n, uint64_t base, uint64_t *offsets, uint64_t *total,
                        hipStream_t s);

@@ -94,6 +94,101 @@ __global__ void record_bounds_kernel(const uint64_t *rec_off, const uint32_t *re
   if (o > cap || cap - o < record_size[b]) flag[0] = 1u;
 }
 
+// Decode side of the dispatcher (lib/src/frame/lz4_frame_decoder.dart:243-271): reads each record's size
+// word, checks it the way the reference does before touching the payload, and splits the blocks into
+// "decode" (dec_len), "copy" (raw_len) and "failed before decoding" (pre_status).
+__global__ void record_read_kernel(RecordReadArgs r) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= r.nblocks) return;
+  const uint64_t off = r.rec_off[b];
+  int32_t pre = LZ4MI_OK;
+  uint32_t size = 0, raw = 0, expect = 0;
+  if (off > r.records_len || r.records_len - off < 4) {
+    pre = LZ4MI_FORMAT_EOF;  // :243-249
+  } else {
+    const uint32_t word = ld32(r.records + off);
+    size = word & 0x7FFFFFFFu;
+    raw = word >> 31;
+    const uint64_t left = r.records_len - off - 4;
+    if (size > r.block_max) pre = LZ4MI_CORRUPT_BLOCK_SIZE;                    // :251-253
+    else if (size > left) pre = LZ4MI_FORMAT_EOF;                               // :255
+    else if (r.block_checksum && left - size < 4) pre = LZ4MI_FORMAT_EOF;       // :258
+    else if (r.block_checksum) expect = ld32(r.records + off + 4 + size);
+  }
+  const bool ok = pre == LZ4MI_OK;
+  r.payload_addr[b] = (uint64_t)(uintptr_t)(r.records + (ok ? off + 4 : 0));
+  r.payload_len[b] = ok ? size : 0u;
+  r.dec_len[b] = ok && !raw ? size : 0u;
+  r.raw_len[b] = ok && raw ? size : 0u;
+  r.slot_off[b] = (uint64_t)b * r.block_max;
+  r.expect[b] = expect;
+  r.pre_status[b] = pre;
+}
+
+// Folds what came before the decode into the per-block results, in the reference's order: size and
+// truncation checks, block checksum (:257-266), then the decoder's own status.
+__global__ void record_finish_kernel(RecordReadArgs r, const uint32_t *hashes, uint32_t *out_len, int32_t *status) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= r.nblocks) return;
+  const int32_t pre = r.pre_status[b];
+  if (pre != LZ4MI_OK) {
+    status[b] = pre;
+    out_len[b] = 0;
+  } else if (r.block_checksum && hashes[b] != r.expect[b]) {
+    status[b] = LZ4MI_CORRUPT_BLOCK_CK;
+    out_len[b] = 0;
+  } else if (r.raw_len[b] || !r.dec_len[b]) {  // stored block (possibly empty): copied, not decoded
+    status[b] = LZ4MI_OK;
+    out_len[b] = r.raw_len[b];
+  }
+}
+
+// Absolute source addresses of block slots for a gather.
+__global__ void slot_addr_kernel(const uint8_t *slots, uint64_t stride, uint32_t nblocks, uint64_t *addr) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nblocks) addr[b] = (uint64_t)(uintptr_t)(slots + (uint64_t)b * stride);
+}
+
+// flags[b] = 1 when compressed block b breaks the LZ4 block format's end-of-block rules: the last five bytes
+// are literals and the last match starts at least twelve bytes before the end of the block.  (The reference's
+// encoders search to the last four bytes and let matches run to the end: lz4_block_encoder.dart:95,118.)
+// One lane per block walks the token chain; the blocks are trusted only as far as their length.
+__global__ void block_conformance_kernel(BatchArgs a, uint32_t *flags) {
+  uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.nblocks) return;
+  const uint8_t *p = a.src + (a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+  const uint32_t c = block_src_len(a, b);
+  uint32_t ip = 0, nmatch = 0, trailing = 0;
+  uint64_t op = 0, last_start = 0;
+  while (ip < c) {
+    const uint32_t tok = p[ip++];
+    uint32_t ll = tok >> 4;
+    if (ll == 15)
+      while (ip < c) {
+        const uint32_t x = p[ip++];
+        ll += x;
+        if (x != 255) break;
+      }
+    ip += ll;
+    op += ll;
+    trailing = ll;
+    if (ip + 2 > c) break;  // last literals
+    ip += 2;
+    uint32_t ml = (tok & 15u) + 4u;
+    if ((tok & 15u) == 15u)
+      while (ip < c) {
+        const uint32_t x = p[ip++];
+        ml += x;
+        if (x != 255) break;
+      }
+    last_start = op;
+    op += ml;
+    nmatch++;
+    trailing = 0;
+  }
+  flags[b] = nmatch && (trailing < 5u || last_start + 12u > op) ? 1u : 0u;
+}
+
 __global__ void put_words_kernel(uint8_t *dst, const uint32_t *words, uint32_t nwords, uint32_t literal0,
                                  int use_literal0) {
   // trailer: end mark (literal 0) followed by device-computed words
@@ -128,6 +223,24 @@ void launch_record_bounds(const uint64_t *rec_off, const uint32_t *record_size, 
   if (!nblocks) return;
   hipLaunchKernelGGL(record_bounds_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, rec_off, record_size,
                      nblocks, cap, flag);
+}
+void launch_record_read(const RecordReadArgs &r, hipStream_t s) {
+  if (!r.nblocks) return;
+  hipLaunchKernelGGL(record_read_kernel, dim3((r.nblocks + 255) / 256), dim3(256), 0, s, r);
+}
+void launch_record_finish(const RecordReadArgs &r, const uint32_t *hashes, uint32_t *out_len, int32_t *status,
+                          hipStream_t s) {
+  if (!r.nblocks) return;
+  hipLaunchKernelGGL(record_finish_kernel, dim3((r.nblocks + 255) / 256), dim3(256), 0, s, r, hashes, out_len,
+                     status);
+}
+void launch_slot_addr(const uint8_t *slots, uint64_t stride, uint32_t nblocks, uint64_t *addr, hipStream_t s) {
+  if (!nblocks) return;
+  hipLaunchKernelGGL(slot_addr_kernel, dim3((nblocks + 255) / 256), dim3(256), 0, s, slots, stride, nblocks, addr);
+}
+void launch_block_conformance(const BatchArgs &a, uint32_t *flags, hipStream_t s) {
+  if (!a.nblocks) return;
+  hipLaunchKernelGGL(block_conformance_kernel, dim3((a.nblocks + 63) / 64), dim3(64), 0, s, a, flags);
 }
 void launch_put_words(uint8_t *dst, const uint32_t *words, uint32_t nwords, bool end_mark, hipStream_t s) {
   hipLaunchKernelGGL(put_words_kernel, dim3(1), dim3(64), 0, s, dst, words, nwords, 0u, end_mark ? 1 : 0);

@@ -208,6 +208,57 @@ class DeviceCodec:
         if st:
             N.raise_status(st, self.ctx.handle)
 
+    def shard_decode(self, records: torch.Tensor, record_offsets: torch.Tensor, options: Lz4FrameOptions,
+                     dictionary: torch.Tensor | None = None, out: torch.Tensor | None = None):
+        """Decode side of the sharded frame: this rank's block records (`records`, uint8, device) at
+        `record_offsets` (int64, relative to `records`).  Returns (slots [nblocks, blockMaxSize],
+        out_len int32 [nblocks], status int32 [nblocks]); block b's bytes are slots[b, :out_len[b]]."""
+        o = _c_options(options)
+        assert record_offsets.dtype == torch.int64 and records.dtype == torch.uint8
+        nb = record_offsets.numel()
+        bmax = options.blockSize.maxBytes
+        if out is None:
+            out = torch.empty((max(nb, 1), bmax), dtype=torch.uint8, device=records.device)
+        out_len = torch.empty(max(nb, 1), dtype=torch.int32, device=records.device)
+        status = torch.empty(max(nb, 1), dtype=torch.int32, device=records.device)
+        self._enter()
+        st = self.L.lz4mi_frame_shard_decode(self.ctx.handle, _ptr(records), records.numel(), _ptr(record_offsets), nb,
+                                             C.byref(o), _ptr(dictionary),
+                                             dictionary.numel() if dictionary is not None else 0, _ptr(out),
+                                             _ptr(out_len), _ptr(status))
+        self._exit()
+        if st:
+            N.raise_status(st, self.ctx.handle)
+        return out[:nb], out_len[:nb], status[:nb]
+
+    def gather_blocks(self, slots: torch.Tensor, lengths: torch.Tensor, dst_offsets: torch.Tensor,
+                      out: torch.Tensor):
+        """Packs slots[b, :lengths[b]] to out[dst_offsets[b]:] (the decoder appends whatever each block yields)."""
+        assert dst_offsets.dtype == torch.int64 and lengths.dtype == torch.int32
+        self._enter()
+        st = self.L.lz4mi_blocks_gather(self.ctx.handle, _ptr(slots), slots.stride(0), _ptr(lengths), _ptr(dst_offsets),
+                                        lengths.numel(), _ptr(out), out.numel())
+        self._exit()
+        if st:
+            N.raise_status(st, self.ctx.handle)
+
+    def block_conformance(self, comp: torch.Tensor, sizes: torch.Tensor, comp_stride: int | None = None) -> torch.Tensor:
+        """int32 [nblocks]: 1 where a compressed block breaks the LZ4 end-of-block rules (the reference's
+        encoders end blocks inside matches, lib/src/block/lz4_block_encoder.dart:95,118)."""
+        nb = sizes.numel()
+        flags = torch.empty(max(nb, 1), dtype=torch.int32, device=comp.device)
+        b = N.Batch()
+        b.d_src = comp.data_ptr()
+        b.src_stride = comp_stride if comp_stride is not None else comp.stride(0)
+        b.d_src_len = sizes.data_ptr()
+        b.nblocks = nb
+        self._enter()
+        st = self.L.lz4mi_blocks_conformance(self.ctx.handle, C.byref(b), _ptr(flags))
+        self._exit()
+        if st:
+            N.raise_status(st, self.ctx.handle)
+        return flags[:nb]
+
     def frame_header(self, options: Lz4FrameOptions) -> bytes:
         o = _c_options(options)
         buf = C.create_string_buffer(32)

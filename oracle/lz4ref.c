@@ -1717,3 +1717,41 @@ int lz4ref_stream_decoder_finish(lz4ref_stream_decoder *d) { /* :415-426 */
   }
   return LZ4REF_FORMAT_EOF;
 }
+
+/* Not a reference function: tells whether a compressed block obeys the LZ4 block format's
+ * end-of-block rules (last five bytes literals, last match starts at least twelve bytes before the
+ * end).  The reference's encoders do not (lib/src/block/lz4_block_encoder.dart:95,118: the search
+ * runs to totalLength-4 and matches extend to the last byte); the checker counts such blocks. */
+int lz4ref_block_conformant(const uint8_t *src, size_t c) {
+  size_t ip = 0, nmatch = 0, trailing = 0;
+  uint64_t op = 0, last_start = 0;
+  while (ip < c) {
+    unsigned tok = src[ip++];
+    size_t ll = tok >> 4;
+    if (ll == 15) {
+      while (ip < c) {
+        unsigned x = src[ip++];
+        ll += x;
+        if (x != 255) break;
+      }
+    }
+    ip += ll;
+    op += ll;
+    trailing = ll;
+    if (ip + 2 > c) break;
+    ip += 2;
+    size_t ml = (tok & 15u) + 4u;
+    if ((tok & 15u) == 15u) {
+      while (ip < c) {
+        unsigned x = src[ip++];
+        ml += x;
+        if (x != 255) break;
+      }
+    }
+    last_start = op;
+    op += ml;
+    nmatch++;
+    trailing = 0;
+  }
+  return !(nmatch && (trailing < 5 || last_start + 12 > op));
+}

@@ -204,6 +204,10 @@ int lz4ref_stream_decoder_next(lz4ref_stream_decoder *d, int *has_output, const 
 int lz4ref_stream_decoder_finish(lz4ref_stream_decoder *d);
 void lz4ref_stream_decoder_free(lz4ref_stream_decoder *d);
 
+/* Checker only (no reference counterpart): 1 when the compressed block obeys the LZ4 block format's
+ * end-of-block rules, 0 when it ends the way the reference's encoders allow (lz4_block_encoder.dart:95,118). */
+int lz4ref_block_conformant(const uint8_t *src, size_t c);
+
 #ifdef __cplusplus
 }
 #endif

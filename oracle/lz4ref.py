@@ -93,6 +93,7 @@ def lib():
         L.lz4ref_block_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64]
         L.lz4ref_block_decompress_into.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lz4ref_block_conformant.argtypes = [C.c_char_p, C.c_size_t]
         L.lz4ref_xxh32.restype = C.c_uint32
         L.lz4ref_xxh32.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         L.lz4ref_xxh32_init.argtypes = [C.POINTER(_XxhState), C.c_uint32]
@@ -210,6 +211,12 @@ def block_decompress_into(src: bytes, prefix: bytes = b"", max_length: int | Non
     if st:
         _raise(st)
     return buf.raw[: out.value]
+
+
+def block_conformant(comp: bytes) -> bool:
+    """True when a compressed block obeys the LZ4 end-of-block rules (checker only, not a reference function)."""
+    comp = bytes(comp)
+    return bool(lib().lz4ref_block_conformant(comp, len(comp)))
 
 
 def xxh32(data: bytes, seed: int = 0) -> int:

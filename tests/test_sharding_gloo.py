@@ -100,3 +100,68 @@ def test_shard_range_partitions_everything():
             spans = [shard_range(n, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+# ------------------------------------------------------------------ decode side
+
+def _decode_worker(rank, world, port, short_blocks, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import lz4ref
+        from lz4_amd.sharding import decoded_offsets, frame_block_table, shard_records
+        from tests.helpers import build_frame
+        from tools.corpus import corpus
+        data = corpus(9 if short_blocks else 8).tobytes()
+        if short_blocks:  # non-final blocks that do not fill blockMaxSize (the format allows it)
+            blocks, a, k = [], 0, 0
+            while a < len(data):
+                chunk = data[a:a + (65536, 4464, 65536, 1, 65536, 33391)[k % 6]]
+                a += len(chunk)
+                k += 1
+                c = lz4ref.block_compress_fast(chunk)
+                blocks.append((c, chunk, False) if len(c) < len(chunk) else (chunk, chunk, True))
+            frame = build_frame(flg=0x70, bd=0x40, blocks=blocks, xxh32=lz4ref.xxh32)
+        else:
+            frame = lz4ref.frame_encode(data, lz4ref.frame_options(block_size_id=4, block_checksum=True,
+                                                                   content_checksum=True))
+        # the host walk (the product's C function, host only) and this rank's share of the records
+        info, offs, end = frame_block_table(frame)
+        assert end == len(frame) and info["block_max_size"] == 65536 and info["block_checksum"]
+        lo, hi, first, last = shard_records(offs, info["body_end"], rank, world)
+        window = frame[first:last]
+        # the per-rank decode, played by the CPU oracle standing in for the device
+        outs = []
+        for k in range(lo, hi):
+            o = int(offs[k]) - first
+            word = int.from_bytes(window[o:o + 4], "little")
+            size = word & 0x7FFFFFFF
+            payload = window[o + 4:o + 4 + size]
+            assert lz4ref.xxh32(payload) == int.from_bytes(window[o + 4 + size:o + 8 + size], "little")
+            outs.append(payload if word >> 31 else lz4ref.block_decompress_into(payload, b"", 65536))
+        sizes = torch.tensor([len(x) for x in outs], dtype=torch.int32)
+        mine, total = decoded_offsets(sizes)  # product code: size exchange + prefix sum
+        buf = torch.zeros(int(total), dtype=torch.uint8)
+        for off, x in zip(mine.tolist(), outs):
+            buf[off:off + len(x)] = torch.frombuffer(bytearray(x), dtype=torch.uint8)
+        dist.all_reduce(buf)  # disjoint ranges: summing == concatenating
+        if rank == 0:
+            q.put(bytes(buf.numpy()) == lz4ref.frame_decode(frame) == data)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("short_blocks", [False, True])
+def test_two_rank_decode_scatter_gloo(short_blocks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decode_worker, args=(r, 2, port, short_blocks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=10)
