@@ -263,6 +263,7 @@ def main():
         wall = float(t.item())
 
     # ---- correctness of what was timed (outside the timed region)
+    codec.fence = True  # from here on the codec's stream is ordered against torch's
     assert int(keep["st_d"].abs().sum()) == 0, "block status != OK"
     assert torch.equal(out.reshape(-1), src), "decode(encode(x)) != x"
     extra = {}
