@@ -65,7 +65,7 @@ enum {
   LZ4MI_DST_TOO_SMALL = 71,          /* caller's destination buffer cannot hold the result */
   LZ4MI_NEED_DICT = 72,              /* lz4mi_frame_decode_next: call again with the dictionary */
   LZ4MI_STREAM_NEED_INPUT = 74,      /* lz4mi_frame_decoder_next: nothing more can be decoded from the bytes fed so far */
-  LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent blocks through the shard calls, blocks of 16 MiB and more) */
+  LZ4MI_UNSUPPORTED_HERE = 73        /* feature outside this library's path (dependent blocks through the shard calls, blocks of 2 GiB and more) */
 };
 
 /* Dart exception class name / message for a status (static strings). */

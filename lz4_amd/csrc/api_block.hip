@@ -370,7 +370,7 @@ int32_t compress_one(lz4mi_ctx *c, int kind, const uint8_t *src, size_t n, const
   if (out_len) *out_len = 0;
   if (param < 1) return LZ4MI_RANGE;
   if (n == 0) return LZ4MI_OK;  // lz4_block_encoder.dart:45-48
-  if (n > kPosMask - 65536u - 8u) return LZ4MI_UNSUPPORTED_HERE;  // table positions are 24-bit
+  if (n > 0x7FFFFFF0u - 65536u) return LZ4MI_UNSUPPORTED_HERE;  // positions are 31-bit on the device
   if (!dict) dict_len = 0;
   OneResult r;
   size_t b = bound(n);

@@ -17,7 +17,9 @@
 // the interior re-hash (:139-145) touches min(length-4, d) positions.
 //
 // Table: 65536 x u32 per wavefront slot in HBM/L2, entry = generation<<24 | (pos+1);
-// a stale generation reads as empty, so a slot is reused without clearing.
+// a stale generation reads as empty, so a slot is reused without clearing.  Blocks whose positions
+// do not fit 24 bits (dictionary + block of 16 MiB and more: one lz4Compress call on a large buffer)
+// run the WIDE variant: entry = pos+1, the slot cleared in front of the block.
 // A shared dictionary is primed once into a read-only table consulted when the
 // slot entry is empty (dictionary positions are always smaller than block positions).
 #include "encode_common.h"
@@ -256,7 +258,14 @@ __device__ __forceinline__ uint32_t write_sequences(const Win &w, lds_u32 *desc,
   return op + rdlane(incl, kWave - 1);
 }
 
-template <bool HAS_DICT, bool LINKED>
+// Position held by a table entry, or -1.
+template <bool WIDE>
+__device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen) {
+  if (WIDE) return (int32_t)e - 1;
+  return (e >> kPosBits) == gen ? (int32_t)(e & kPosMask) - 1 : -1;
+}
+
+template <bool HAS_DICT, bool LINKED, bool WIDE>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
@@ -269,8 +278,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   out_len = 0;
   if (n == 0) return LZ4MI_OK;  // :45-48
   if ((uint64_t)cap < (uint64_t)n + n / 255u + 16u) return LZ4MI_DST_TOO_SMALL;
-  if (total > kPosMask - 1) return LZ4MI_UNSUPPORTED_HERE;  // table positions are 24-bit
-  const uint32_t gtag = gen << kPosBits;
+  if (total > (WIDE ? 0x7FFFFFF0u : kPosMask - 1)) return LZ4MI_UNSUPPORTED_HERE;  // position width of the table
+  const uint32_t gtag = WIDE ? 0u : gen << kPosBits;
   uint32_t anchor = D, op = 0;
   PH_DECL
 
@@ -308,8 +317,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         const uint32_t hx = valid ? h : 0u;
         const uint32_t e = tbl_load(T + hx);
         const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[hx] : 0u;
-        if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
-        else if (HAS_DICT && !LINKED) ref = (int32_t)ed - 1;
+        ref = entry_ref<WIDE>(e, gen);
+        if (HAS_DICT && !LINKED && ref < 0) ref = (int32_t)ed - 1;
       }
       uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));  // >= 1, valid lanes form a prefix
 #ifdef LZ4MI_PROFILE
@@ -372,8 +381,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
             h = hash16(seq);
             const uint32_t e = tbl_load(T + h);
             const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[h] : 0u;
-            if ((e >> kPosBits) == gen) ref = (int32_t)(e & kPosMask) - 1;
-            else if (HAS_DICT && !LINKED) ref = (int32_t)ed - 1;
+            ref = entry_ref<WIDE>(e, gen);
+            if (HAS_DICT && !LINKED && ref < 0) ref = (int32_t)ed - 1;
           }
           {  // same-bucket probes of this chunk, nearest earlier lane: 16 bit-plane votes
             uint64_t peers = valid ? ((1ull << lane) - 1ull) : 0ull;
@@ -551,7 +560,7 @@ struct EncodeKArgs {
 };
 typedef const volatile __attribute__((address_space(4))) EncodeKArgs *EncodeKArgsPtr;
 
-template <bool HAS_DICT, bool LINKED>
+template <bool HAS_DICT, bool LINKED, bool WIDE = false>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[4][kClaimSlots];
@@ -587,7 +596,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
   uint32_t b = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
   for (;; b = direct ? 0xffffffffu : nwaves + next_block(ka->counter, lane)) {
     if (b >= ka->a.nblocks) break;
-    if (++gen > kGenMax) {  // generation wrapped: clear the slot
+    if (WIDE || ++gen > kGenMax) {  // generation wrapped (or entries carry no generation): clear the slot
       for (uint32_t k = lane * 4; k < kHashEntries; k += kWave * 4) *(uint4 *)(T + k) = make_uint4(0, 0, 0, 0);
       gen = 1;
     }
@@ -619,7 +628,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
 #ifdef LZ4MI_PROFILE
     if (lane == 0 && b < 65536) g_enc_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
-    int32_t st = encode_block_fast<HAS_DICT, LINKED>(in, out, cap, sh, T, dictT, gen, offA, offB,
+    int32_t st = encode_block_fast<HAS_DICT, LINKED, WIDE>(in, out, cap, sh, T, dictT, gen, offA, offB,
                                                      (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], (lds_u32 *)s_desc[wave], lane,
                                                      out_len);
 #ifdef LZ4MI_PROFILE
@@ -630,7 +639,8 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
       ka->a.status[b] = st;
     }
   }
-  if (lane == 0) ka->sc.slot_gen[slot] = gen;
+  // wide entries would read as tagged ones: the next block on this slot starts with a clear
+  if (lane == 0) ka->sc.slot_gen[slot] = WIDE ? kGenMax : gen;
 #ifdef LZ4MI_PROFILE
   if (lane == 0) atomicMax(&g_enc_phase[13], __builtin_amdgcn_s_memrealtime() - life0);
 #endif
@@ -665,7 +675,13 @@ extern "C" void lz4mi_debug_enc_phases(unsigned long long *out, int reset) {
 
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
                         uint32_t grid, hipStream_t s) {
-  if (a.linked)
+  // blocks whose positions need more than 24 bits (only with uniform lengths: one large block per call)
+  const bool wide = !a.src_len && !a.linked && (uint64_t)a.src_len_uniform + a.dict_len > kPosMask - 2;
+  if (wide && a.dict_len)
+    hipLaunchKernelGGL((encode_fast_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (wide)
+    hipLaunchKernelGGL((encode_fast_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (a.linked)
     hipLaunchKernelGGL((encode_fast_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
   else if (a.dict_len)
     hipLaunchKernelGGL((encode_fast_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);

@@ -28,6 +28,7 @@
 namespace lz4mi {
 
 constexpr uint32_t kNoIns = 0x80000000u;  // index entry: this position is never inserted
+constexpr uint32_t kHcPosMask = 0x7FFFFFFFu;  // the position of an index entry
 
 struct HcIndex {
   uint32_t *cnt;     // 65536 bucket counters, all zero between blocks
@@ -242,7 +243,7 @@ __device__ __forceinline__ void hc_eval_slice(const EncIn &in, const HcIndex &x,
     const uint64_t insm = ballot(ins);
     const uint32_t ordinal = (uint32_t)__builtin_popcountll(insm & ((1ull << lane) - 1ull));
     const bool take = ins && depth + ordinal < max_depth;  // :123 depth bound, flagged entries are not on the chain
-    const uint32_t c = e & kPosMask;
+    const uint32_t c = e & kHcPosMask;
     const bool near = take && P - c <= 0xFFFFu;  // :125-129
     const bool m4 = near && en.y == seq;
     uint32_t ml = 0;
@@ -271,7 +272,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
   out_len = 0;
   if (n == 0) return LZ4MI_OK;  // :57-60
   if ((uint64_t)cap < (uint64_t)n + n / 255u + 16u) return LZ4MI_DST_TOO_SMALL;
-  if (total > kPosMask - 1) return LZ4MI_UNSUPPORTED_HERE;
+  if (total > 0x7FFFFFF0u) return LZ4MI_UNSUPPORTED_HERE;
   uint32_t anchor = D, i = D, op = 0;
 
   if (n >= 4) {  // :86-90
@@ -317,7 +318,7 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
         }
         const uint32_t e = en.x;
         const bool cnd = act && !(e & kNoIns);  // flagged entries are not on the chain
-        const uint32_t c = e & kPosMask;
+        const uint32_t c = e & kHcPosMask;
         const bool near = cnd && p - c <= 0xFFFFu;  // far candidates only consume depth (:125-129)
         bool m4 = near && en.y == seq;
         // a lane with a 4-byte hit holds a match: lanes above the lowest such lane no longer matter
@@ -462,7 +463,7 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   }
   // index capacity: dictionary plus the largest block this batch can contain
   uint64_t max_len = a.src_len ? (a.dst_cap_uniform ? a.dst_cap_uniform : (4u << 20)) : a.src_len_uniform;
-  if (max_len > kPosMask) max_len = kPosMask;
+  if (max_len > 0x7FFFFFF0u) max_len = 0x7FFFFFF0u;
   const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
   const uint64_t budget = 8ull << 30;  // bytes of index scratch
   uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);

@@ -492,6 +492,24 @@ def test_encoder_sequence_shapes_vs_oracle(codec, oracle):
             assert h_slots[b, : len(ref)].tobytes() == ref, (block, b)
 
 
+def test_single_block_of_20_mib_equals_the_oracle(lz, oracle):
+    """lz4Compress takes any length (lib/dart_lz4.dart:60-72): positions past 2^24 use the wide table entries."""
+    from lz4_amd import Lz4CompressionLevel
+    data = corpus(320).tobytes()  # 20 MiB, every block class
+    ref = oracle.block_compress_fast(data)
+    got = lz.lz4Compress(data)
+    assert got == ref
+    assert lz.lz4Decompress(got, decompressedSize=len(data)) == data
+    d = corpus_block(3).tobytes()[:40000]
+    assert lz.lz4Compress(data[: 17 << 20], dictionary=d) == oracle.block_compress_fast(data[: 17 << 20], dictionary=d)
+    # a small block right after on the same context: the slot's wide entries must not leak into it
+    small = corpus_block(5).tobytes()
+    assert lz.lz4Compress(small) == oracle.block_compress_fast(small)
+    # HC past 2^24 positions (run-like data keeps one wavefront quick)
+    big = ramp(9 << 20) + bytes(4 << 20) + ramp(4 << 20) + corpus_block(6).tobytes()
+    assert lz.lz4Compress(big, level=Lz4CompressionLevel.hc) == oracle.block_compress_hc(big)
+
+
 def test_encoder_with_dictionary_vs_oracle(lz, oracle):
     text = corpus_block(3).tobytes()
     d32k = text[:32768]
@@ -677,6 +695,42 @@ def test_large_batch_roundtrip_and_sampled_oracle(codec, oracle):
     slots2, sizes2, _ = codec.compress_blocks(src, 65536)
     assert torch.equal(sizes2, sizes)
     assert torch.equal(slots2[7, : int(h_sizes[7])], slots[7, : int(h_sizes[7])])
+
+
+def test_full_size_corpus_every_block_equals_the_oracle(codec, oracle):
+    """BASELINE configs[1] at full size: all 16 384 blocks of the 1 GiB corpus (seed 0) through the fast
+    encoder, every block compared with the oracle's bytes (oracle on a thread pool), then strict decode."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    nb = 16384
+    data = corpus(nb)
+    src = torch.from_numpy(data).cuda()
+    slots, sizes, status = codec.compress_blocks(src, 65536)
+    assert int(status.abs().sum()) == 0
+    out, out_len, st = codec.decompress_blocks(slots, sizes, 65536, strict=True)
+    assert int(st.abs().sum()) == 0 and torch.equal(out.reshape(-1), src)
+    del out
+    h_slots = slots.cpu().numpy()
+    h_sizes = sizes.cpu().numpy()
+    L = oracle.lib()
+    bound = oracle.compress_bound(65536)
+    base = data.ctypes.data
+
+    def check(span):
+        buf = C.create_string_buffer(bound)
+        n = C.c_size_t(0)
+        bad = []
+        for b in range(*span):
+            L.lz4ref_block_compress_fast(C.c_char_p(base + b * 65536), 65536, None, 0, 1, buf, bound, C.byref(n))
+            if n.value != h_sizes[b] or h_slots[b, : n.value].tobytes() != buf.raw[: n.value]:
+                bad.append(b)
+        return bad
+
+    spans = [(lo, min(nb, lo + 128)) for lo in range(0, nb, 128)]
+    with ThreadPoolExecutor(16) as ex:
+        bad = [b for part in ex.map(check, spans) for b in part]
+    assert not bad, bad[:10]
 
 
 def test_device_frame_equals_host_frame(codec, lz, oracle):
