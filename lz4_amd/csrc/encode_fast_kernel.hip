@@ -29,6 +29,9 @@ namespace lz4mi {
 
 #ifdef LZ4MI_PROFILE
 __device__ unsigned long long g_enc_phase[PH_SLOTS];
+#endif
+#if defined(LZ4MI_PROFILE) || defined(LZ4MI_SPANS)
+#define LZ4MI_ENC_SPANS 1
 __device__ unsigned long long g_enc_span[2 * 65536];  // per block: start and end (100 MHz ticks)
 #endif
 
@@ -625,13 +628,13 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
     const uint32_t cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
     const uint32_t *dictT = ka->sc.dict_table;
     uint32_t out_len = 0;
-#ifdef LZ4MI_PROFILE
+#ifdef LZ4MI_ENC_SPANS
     if (lane == 0 && b < 65536) g_enc_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     int32_t st = encode_block_fast<HAS_DICT, LINKED, WIDE>(in, out, cap, sh, T, dictT, gen, offA, offB,
                                                      (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], (lds_u32 *)s_desc[wave], lane,
                                                      out_len);
-#ifdef LZ4MI_PROFILE
+#ifdef LZ4MI_ENC_SPANS
     if (lane == 0 && b < 65536) g_enc_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (lane == 0) {
@@ -660,10 +663,12 @@ void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_ta
   }
 }
 
-#ifdef LZ4MI_PROFILE
+#ifdef LZ4MI_ENC_SPANS
 extern "C" void lz4mi_debug_enc_spans(unsigned long long *out, int n) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_span), sizeof(unsigned long long) * 2 * n);
 }
+#endif
+#ifdef LZ4MI_PROFILE
 extern "C" void lz4mi_debug_enc_phases(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_phase), sizeof(unsigned long long) * PH_SLOTS);
   if (reset) {
