@@ -128,7 +128,7 @@ extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   DevBuf *bufs[] = {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
                     &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
                     &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
-                    &c->hc_chain, &c->hc_cnt, &c->hc_floor, &c->order};
+                    &c->hc_chain, &c->hc_floor, &c->order};
   for (DevBuf *b : bufs) b->release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);

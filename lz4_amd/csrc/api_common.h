@@ -59,8 +59,8 @@ struct lz4mi_ctx {
   // per-block bookkeeping
   lz4mi::DevBuf comp, comp_len, status, stored_word, payload_addr, payload_len, record_size, rec_off,
       hashes, words, total;
-  // HC encoder: per-slot position index (rank + sorted), bucket counters and floors
-  lz4mi::DevBuf hc_chain, hc_cnt, hc_floor;
+  // HC encoder: per-slot position index (rank, sorted, sort scratch) and bucket floors
+  lz4mi::DevBuf hc_chain, hc_floor;
   // decoder: queue position -> block index of a launch (long blocks first)
   lz4mi::DevBuf order;
 

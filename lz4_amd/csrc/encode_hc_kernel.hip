@@ -24,17 +24,22 @@
 // step.
 #include "api_common.h"
 #include "encode_common.h"
+#include "profile.h"
 
 namespace lz4mi {
+
+#ifdef LZ4MI_PROFILE
+__device__ unsigned long long g_hc_phase[PH_SLOTS];  // 0 index build, 1 parse, 15 total (cycles)
+#endif
 
 constexpr uint32_t kNoIns = 0x80000000u;  // index entry: this position is never inserted
 constexpr uint32_t kHcPosMask = 0x7FFFFFFFu;  // the position of an index entry
 
 struct HcIndex {
-  uint32_t *cnt;     // 65536 bucket counters, all zero between blocks
   uint32_t *floor_;  // 65536: lowest rank of the bucket a walk can still reach
   uint32_t *rank;    // per position of dict||src
   uint2 *sorted;     // per rank: position (| kNoIns) and the four bytes at that position (what a walk compares first)
+  uint2 *tmp;        // the entries after the first sort pass
 };
 
 // Arrays of a slot are rewritten for every block by the wavefront that owns the slot; workgroup
@@ -82,72 +87,115 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
   return rdlane(v, kWave - 1);
 }
 
-// Index of one block: counting sort of the positions 0 .. T-1 by bucket, stable in position.
+// lanes (among the valid ones) whose 8-bit digit equals this lane's
+__device__ __forceinline__ uint64_t same_digit(uint32_t dg, bool valid) {
+  uint64_t same = ballot(valid);
+#pragma unroll
+  for (uint32_t bit = 0; bit < 8; bit++) {
+    const bool set = (dg >> bit) & 1u;
+    const uint64_t m = ballot(set);
+    same &= set ? m : ~m;
+  }
+  return valid ? same : 0ull;
+}
+
+// One stable counting-sort step over a chunk of 64 elements in order: where this lane's element goes.
+// next[dg] = next free place of digit dg (LDS, owned by this wavefront); lanes of one chunk that share a
+// digit take consecutive places in lane order, the last of them moves the counter on.
+__device__ __forceinline__ uint32_t radix_place(lds_u32 *next, uint32_t dg, bool valid, uint32_t lane) {
+  const uint64_t same = same_digit(dg, valid);
+  const uint32_t last = same ? 63u - (uint32_t)__builtin_clzll(same) : lane;
+  const uint32_t before = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+  uint32_t old = 0;
+  if (valid && lane == last) {
+    old = next[dg];
+    next[dg] = old + (uint32_t)__builtin_popcountll(same);
+  }
+  return (uint32_t)__shfl((int)old, (int)last) + before;
+}
+
+// Index of one block: the positions 0 .. T-1 sorted by (bucket, position).  A two-pass radix sort on the
+// 16-bit bucket, low byte first, each pass a stable counting sort whose 256 counters live in LDS: the
+// scattered writes of a pass go to 256 append streams (lines fill up in L2 and leave as whole lines)
+// instead of 65 536 buckets spread over the slot's memory.  hist: 512 LDS words of this wavefront.
 template <bool HAS_DICT>
-__device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x, uint32_t T, uint32_t lane) {
+__device__ __forceinline__ void hc_build_index(const EncIn &in, const HcIndex &x, uint32_t T, lds_u32 *hist,
+                                               uint32_t lane) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
-  constexpr uint32_t U = 4;  // chunks of 64 positions in flight, so that their memory round trips overlap
-  // 1: bucket sizes; rank[p] = number of earlier positions in p's bucket
+  constexpr uint32_t U = 4;  // chunks of 64 positions whose loads are in flight together
+  // 1: histograms of both bytes of the bucket
+  for (uint32_t k = lane; k < 512u; k += kWave) hist[k] = 0;
   for (uint32_t base = 0; base < T; base += U * kWave) {
-    uint32_t h[U], old[U], last[U], before[U];
-    bool valid[U];
+    uint32_t h[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
       const uint32_t p = base + u * kWave + lane;
-      valid[u] = p < T;
-      h[u] = valid[u] ? hash16(in_ld32<HAS_DICT>(in, p)) : 0u;
+      h[u] = p < T ? hash16(in_ld32<HAS_DICT>(in, p)) : 0x10000u;
     }
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
-      const uint64_t same = same_bucket(h[u], valid[u]);
-      last[u] = same ? 63u - (uint32_t)__builtin_clzll(same) : lane;
-      before[u] = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-      old[u] = 0;
-      if (valid[u] && lane == last[u])  // chunks are issued in position order, so a bucket met twice still counts in order
-        old[u] = __hip_atomic_fetch_add(x.cnt + h[u], (uint32_t)__builtin_popcountll(same), __ATOMIC_RELAXED,
-                                        __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < U; u++) {
-      const uint32_t o = (uint32_t)__shfl((int)old[u], (int)last[u]);
-      if (valid[u]) xst(x.rank + base + u * kWave + lane, o + before[u]);
+      if (h[u] < 0x10000u) {
+        (void)__hip_atomic_fetch_add(hist + (h[u] & 255u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        (void)__hip_atomic_fetch_add(hist + 256u + (h[u] >> 8), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
     }
   }
-  // 2: exclusive prefix sum of the sizes = first rank of every bucket; counters back to zero
-  uint32_t carry = 0;
-  for (uint32_t k = 0; k < kHashEntries; k += U * kWave) {
-    uint32_t v[U];
+  // 2: exclusive prefix sums: first place of every digit (four counters per lane and histogram)
 #pragma unroll
-    for (uint32_t u = 0; u < U; u++) v[u] = xld(x.cnt + k + u * kWave + lane);
-#pragma unroll
-    for (uint32_t u = 0; u < U; u++) {
-      const uint32_t inc = wave_incl_scan(v[u]);
-      xst(x.floor_ + k + u * kWave + lane, carry + inc - v[u]);
-      xst(x.cnt + k + u * kWave + lane, 0u);
-      carry += rdlane(inc, kWave - 1);
-    }
+  for (uint32_t t = 0; t < 2; t++) {
+    lds_u32 *hh = hist + 256u * t + 4u * lane;
+    const uint32_t v0 = hh[0], v1 = hh[1], v2 = hh[2], v3 = hh[3];
+    const uint32_t sum = v0 + v1 + v2 + v3;
+    const uint32_t ex = wave_incl_scan(sum) - sum;
+    hh[0] = ex;
+    hh[1] = ex + v0;
+    hh[2] = ex + v0 + v1;
+    hh[3] = ex + v0 + v1 + v2;
   }
-  // 3: scatter
+  // 3: by the low byte, input order -> tmp
   for (uint32_t base = 0; base < T; base += U * kWave) {
-    uint32_t h[U], ord[U], sq[U];
+    uint32_t sq[U];
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
       const uint32_t p = base + u * kWave + lane;
       sq[u] = p < T ? in_ld32<HAS_DICT>(in, p) : 0u;
-      h[u] = hash16(sq[u]);
-      ord[u] = p < T ? xld(x.rank + p) : 0u;
     }
-    uint32_t st[U];
-#pragma unroll
-    for (uint32_t u = 0; u < U; u++) st[u] = xld(x.floor_ + h[u]);
 #pragma unroll
     for (uint32_t u = 0; u < U; u++) {
       const uint32_t p = base + u * kWave + lane;
-      if (p < T) {
-        xst_entry(x.sorted + st[u] + ord[u], p, sq[u]);
-        xst(x.rank + p, st[u] + ord[u]);
+      const uint32_t o = radix_place(hist, hash16(sq[u]) & 255u, p < T, lane);
+      if (p < T) xst_entry(x.tmp + o, p, sq[u]);
+    }
+  }
+  vm_quiesce();
+  // 4: by the high byte, tmp order -> sorted; rank[p] = where p went
+  for (uint32_t base = 0; base < T; base += U * kWave) {
+    uint2 en[U];
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t i = base + u * kWave + lane;
+      en[u] = i < T ? xld_entry(x.tmp + i) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < U; u++) {
+      const uint32_t i = base + u * kWave + lane;
+      const uint32_t o = radix_place(hist + 256u, hash16(en[u].y) >> 8, i < T, lane);
+      if (i < T) {
+        xst_entry(x.sorted + o, en[u].x, en[u].y);
+        xst(x.rank + en[u].x, o);
       }
     }
+  }
+  vm_quiesce();
+  // 5: first rank of every bucket that holds a position
+  uint32_t prev_key = 0x10000u;  // bucket of the entry in front of the chunk
+  for (uint32_t base = 0; base < T; base += kWave) {
+    const uint32_t i = base + lane;
+    const uint32_t key = i < T ? hash16(xld_entry(x.sorted + i).y) : 0x10001u;
+    uint32_t before = (uint32_t)__shfl_up((int)key, 1);
+    if (lane == 0) before = prev_key;
+    if (i < T && key != before) xst(x.floor_ + key, i);
+    prev_key = rdlane(key, kWave - 1);
   }
   // the last three dictionary positions are never inserted (:105-109 stops at dictLength - 4)
   if (HAS_DICT && D != 0) {
@@ -264,7 +312,7 @@ __device__ __forceinline__ void hc_eval_slice(const EncIn &in, const HcIndex &x,
 
 template <bool HAS_DICT>
 __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out, uint32_t cap, uint32_t max_depth,
-                                                   const HcIndex x, uint32_t lane, uint32_t &out_len) {
+                                                   const HcIndex x, lds_u32 *hist, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t plimit = in.plimit, elimit = in.elimit;  // both == total unless spec-conformant
@@ -274,9 +322,11 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
   if ((uint64_t)cap < (uint64_t)n + n / 255u + 16u) return LZ4MI_DST_TOO_SMALL;
   if (total > 0x7FFFFFF0u) return LZ4MI_UNSUPPORTED_HERE;
   uint32_t anchor = D, i = D, op = 0;
+  PH_DECL
 
   if (n >= 4) {  // :86-90
-    hc_build_index<HAS_DICT>(in, x, total - 3, lane);
+    hc_build_index<HAS_DICT>(in, x, total - 3, hist, lane);
+    PH(0);
     while (i + 4 <= plimit) {  // :116
       const uint32_t p = i + lane;
       const bool valid = p + 4 <= plimit;  // a prefix of the lanes
@@ -378,14 +428,25 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
   }
   const uint32_t last = total - anchor;  // :193-196
   if (last != 0) op = emit_last_literals(out, op, in.src + (anchor - D), last, lane);
+  PH(1);
+  PH_FLUSH(g_hc_phase, lane);
   out_len = op;
   return LZ4MI_OK;
 }
 
+#ifdef LZ4MI_PROFILE
+extern "C" void lz4mi_debug_hc_phases(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hc_phase), sizeof(unsigned long long) * PH_SLOTS);
+  if (reset) {
+    unsigned long long z[PH_SLOTS] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hc_phase), z, sizeof z);
+  }
+}
+#endif
+
 struct HcScratch {
-  uint32_t *cnt;       // nslots * 65536, zero
   uint32_t *floor_;    // nslots * 65536
-  uint32_t *index;     // nslots * 3 * stride words: rank[stride], sorted[stride] (two words per entry)
+  uint32_t *index;     // nslots * 5 * stride words: rank[stride], sorted[stride], tmp[stride] (two words per entry)
   uint64_t stride;     // positions per slot
 };
 
@@ -401,15 +462,17 @@ typedef const volatile __attribute__((address_space(4))) HcKArgs *HcKArgsPtr;
 
 template <bool HAS_DICT, bool LINKED>
 __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcScratch, uint32_t *) {
+  __shared__ uint32_t s_hist[4][512];
   HcKArgsPtr ka = (HcKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t slot = uni(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave);
+  lds_u32 *hist = (lds_u32 *)s_hist[uni(threadIdx.x / kWave)];
   const uint64_t stride = ka->sc.stride;
   HcIndex x;
-  x.cnt = ka->sc.cnt + (size_t)slot * kHashEntries;
   x.floor_ = ka->sc.floor_ + (size_t)slot * kHashEntries;
-  x.rank = ka->sc.index + (size_t)slot * 3 * stride;
+  x.rank = ka->sc.index + (size_t)slot * 5 * stride;
   x.sorted = (uint2 *)(x.rank + stride);
+  x.tmp = x.sorted + stride;
   const uint32_t max_depth = ka->max_depth;
   // with a wavefront per block the block index is the wavefront's own (no contended queue pops at start)
   const uint32_t nwaves = gridDim.x * (blockDim.x / kWave);
@@ -444,7 +507,7 @@ __global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcS
     const uint32_t cap = uni(dst_cap ? dst_cap[b] : ka->a.dst_cap_uniform);
     uint32_t out_len = 0;
     int32_t st = (uint64_t)in.total > stride ? (int32_t)LZ4MI_UNSUPPORTED_HERE
-                                             : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, x, lane, out_len);
+                                             : encode_block_hc<HAS_DICT>(in, out, cap, max_depth, x, hist, lane, out_len);
     if (lane == 0) {
       ka->a.out_len[b] = out_len;
       ka->a.status[b] = st;
@@ -467,17 +530,11 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
   const uint64_t budget = 8ull << 30;  // bytes of index scratch
   uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);
-  while (slots > 4 && (uint64_t)slots * stride * 12 > budget) slots -= 4;
+  while (slots > 4 && (uint64_t)slots * stride * 20 > budget) slots -= 4;
   const size_t tbl = (size_t)slots * kHashEntries * sizeof(uint32_t);
-  if (tbl > c->hc_cnt.cap) {  // counters must start at zero; the kernel leaves them at zero
-    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-    LZ4MI_HIP(c, c->hc_cnt.ensure(tbl));
-    LZ4MI_HIP(c, hipMemsetAsync(c->hc_cnt.p, 0, c->hc_cnt.cap, c->stream));
-  }
   LZ4MI_HIP(c, c->hc_floor.ensure(tbl));
-  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 12));
+  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 20));
   HcScratch sc;
-  sc.cnt = c->hc_cnt.as<uint32_t>();
   sc.floor_ = c->hc_floor.as<uint32_t>();
   sc.index = c->hc_chain.as<uint32_t>();
   sc.stride = stride;
