@@ -183,7 +183,7 @@ int32_t lz4mi_decompress_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t str
 /* lz4mi_decompress_batch for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
  * reference.  Same arguments, same results; the launch's queue words and its block order list
- * live in a static device array of the library (4 MiB + 256 B per GPU, held until the process
+ * live in a static device array of the library (8 MiB + 256 B per GPU, held until the process
  * ends) instead of context buffers, so the call performs no hipMalloc/hipFree.
  * At most LZ4MI_STATIC_MAX_BLOCKS blocks per call: more -> LZ4MI_UNSUPPORTED_HERE with the
  * reason in lz4mi_last_backend_error(ctx), nothing launched.  All contexts on one GPU share

@@ -67,13 +67,13 @@ static thread_local std::string g_create_error;
 
 // Device memory of lz4mi_decompress_batch_static: the decoder's queue words and its block order list, which
 // lz4mi_decompress_batch keeps in buffers the context allocates.  Every GPU the library runs on holds its own
-// copy of this array (4 MiB + 256 B) until the process ends.  `scratch` is a host-side stand-in for the symbol:
+// copy of this array (8 MiB + 256 B) until the process ends.  `scratch` is a host-side stand-in for the symbol:
 // host code uses the per-device address that lz4mi_ctx_create looks up, never the name.  (No `used`
 // attribute: the compiler exports the symbol to the runtime because host code names it; with `used`
 // it stays local to the code object and the runtime cannot find it.)
 constexpr uint32_t kStaticMaxBlocks = LZ4MI_STATIC_MAX_BLOCKS;
 constexpr uint32_t kStaticHead = 64;  // words in front of the order list (queue heads)
-static __device__ __align__(256) uint32_t scratch[kStaticHead + kStaticMaxBlocks];
+static __device__ __align__(256) uint32_t scratch[kStaticHead + 2 * kStaticMaxBlocks];  // two order words per block
 
 static int32_t create_fail(lz4mi_ctx *c, hipError_t e, const char *what) {
   g_create_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -201,7 +201,7 @@ int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a_in, int64_t accelerat
   return LZ4MI_OK;
 }
 
-// counters: kNumCounters queue words; order: one word per block.  Both are device memory that nothing
+// counters: kNumCounters queue words; order: two words per block.  Both are device memory that nothing
 // else on the stream uses while the launch runs.
 static int32_t run_decompress_with(lz4mi_ctx *c, const BatchArgs &a_in, bool strict, uint32_t *counters, uint32_t *order) {
   if (a_in.nblocks == 0) return LZ4MI_OK;
@@ -224,7 +224,7 @@ static int32_t run_decompress_with(lz4mi_ctx *c, const BatchArgs &a_in, bool str
 
 int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict) {
   if (a.nblocks == 0) return LZ4MI_OK;
-  LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * sizeof(uint32_t)));
+  LZ4MI_HIP(c, c->order.ensure((size_t)a.nblocks * 2 * sizeof(uint32_t)));
   return run_decompress_with(c, a, strict, c->d_counters, c->order.as<uint32_t>());
 }
 

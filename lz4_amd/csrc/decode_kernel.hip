@@ -946,8 +946,13 @@ void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
 // A launch ends when its longest block does, and the queue hands blocks out in order: a long block
 // far down the queue starts late.  What a block costs the decoder shows in its size: literal-only
 // blocks (compressed >= about the output size) and run-like blocks (a few bytes) are streamed, the
-// ones in between are sequence after sequence on one wavefront.  Those go to the front of the queue.
-__global__ __launch_bounds__(256) void decode_order_kernel(BatchArgs a, uint32_t *cnt, uint32_t *order) {
+// ones in between are sequence after sequence on one wavefront ("heavy").  Heavy blocks are bound by
+// instruction issue, streamed ones by memory bandwidth, so the queue mixes them: `mix` streamed
+// blocks behind every heavy one while both kinds last.  mix = 0 puts every heavy block in front
+// (right for a launch of few blocks per wavefront, which ends with its slowest block); a launch of
+// many blocks per wavefront runs both kinds side by side from start to end.
+// Step 1: kind and index within the kind of every block (tag[b] = heavy << 31 | index), totals in cnt[0..1].
+__global__ __launch_bounds__(256) void decode_order_count_kernel(BatchArgs a, uint32_t *cnt, uint32_t *tag) {
   const uint32_t lane = lane_id();
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = b < a.nblocks;
@@ -965,9 +970,31 @@ __global__ __launch_bounds__(256) void decode_order_kernel(BatchArgs a, uint32_t
   bh = uni(bh);
   bl = uni(bl);
   const uint64_t below = (1ull << lane) - 1ull;
-  if (heavy) order[bh + (uint32_t)__builtin_popcountll(hm & below)] = b;
-  else if (valid) order[a.nblocks - 1u - (bl + (uint32_t)__builtin_popcountll(lm & below))] = b;
+  if (heavy) tag[b] = 0x80000000u | (bh + (uint32_t)__builtin_popcountll(hm & below));
+  else if (valid) tag[b] = bl + (uint32_t)__builtin_popcountll(lm & below);
 }
+
+// Step 2: queue positions.  G = min(H, L / mix) groups of one heavy block and `mix` streamed ones, then
+// the heavy blocks that are left, then the streamed ones that are left.
+__global__ __launch_bounds__(256) void decode_order_place_kernel(uint32_t nblocks, uint32_t mix, const uint32_t *cnt,
+                                                                 const uint32_t *tag, uint32_t *order) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  const uint32_t H = cnt[0], L = cnt[1];
+  const uint32_t t = tag[b], k = t & 0x7FFFFFFFu;
+  uint32_t pos;
+  if (mix == 0) {
+    pos = (t >> 31) ? k : H + k;
+  } else {
+    const uint32_t G = H < L / mix ? H : L / mix;
+    if (t >> 31) pos = k < G ? k * (mix + 1u) : G * (mix + 1u) + (k - G);
+    else pos = k < G * mix ? (k / mix) * (mix + 1u) + 1u + k % mix : G * (mix + 1u) + (H - G) + (k - G * mix);
+  }
+  order[pos] = b;
+}
+
+constexpr uint32_t kMix = 3;            // streamed blocks per heavy block in the queue of a long launch
+constexpr uint32_t kMixFromRounds = 8;  // a launch is long from this many blocks per resident wavefront
 
 // Resident wavefronts (= workgroups) per CU of a decode kernel: bounded by its LDS and registers.
 template <typename K>
@@ -982,13 +1009,25 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
   // one wavefront per workgroup; as many as stay resident (one that is not would hold its first block back)
   static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>), resident_per_cu(decode_kernel<false, true>),
                                      resident_per_cu(decode_kernel<true, false>), resident_per_cu(decode_kernel<true, true>)};
+  // streamed blocks behind every heavy one in the queue of a long launch (LZ4MI_DEC_MIX overrides; 0 = heavy first)
+  static const int mix_env = [] {
+    const char *e = getenv("LZ4MI_DEC_MIX");
+    return e ? atoi(e) : -1;
+  }();
   const bool pre = a.dict_len != 0;
   const uint32_t slots = cu_count * per_cu[(strict ? 2 : 0) + (pre ? 1 : 0)];
   const uint32_t grid = a.nblocks < slots ? a.nblocks : slots;
-  if (order && a.nblocks > grid)  // only a queued launch has an order to choose
-    hipLaunchKernelGGL(decode_order_kernel, dim3((a.nblocks + 255) / 256), dim3(256), 0, s, a, order_cnt, order);
-  else
+  if (order && a.nblocks > grid) {  // only a queued launch has an order to choose
+    // few blocks per wavefront: the launch ends with its slowest block, heavy blocks go first
+    uint32_t mix = a.nblocks >= kMixFromRounds * grid ? kMix : 0u;
+    if (mix_env >= 0) mix = (uint32_t)mix_env;
+    uint32_t *tag = order + a.nblocks;
+    const dim3 g((a.nblocks + 255) / 256), blk(256);
+    hipLaunchKernelGGL(decode_order_count_kernel, g, blk, 0, s, a, order_cnt, tag);
+    hipLaunchKernelGGL(decode_order_place_kernel, g, blk, 0, s, a.nblocks, mix, order_cnt, tag, order);
+  } else {
     order = nullptr;
+  }
   dim3 g(grid), blk(64);
   if (strict) {
     if (pre) hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, order);

@@ -68,8 +68,8 @@ struct ChainArgs {
 };
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s);
-// counter: the queue head, zero at launch; order: one word per block (or null: index order),
-// order_cnt: two words, zero at launch.  The grid is sized to the wavefronts that stay resident.
+// counter: the queue head, zero at launch; order: TWO words per block (queue order, and scratch for
+// building it), or null: index order; order_cnt: two words, zero at launch.  The grid is sized to the wavefronts that stay resident.
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
                    uint32_t cu_count, hipStream_t s);
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
