@@ -360,6 +360,11 @@ constexpr uint32_t kMatMax = 19 + 5 * 255 + 254;  // longest match (up to six ex
 constexpr uint32_t kSeqIn = 8 + kLitMax + 8 + 8;  // compressed bytes a batched sequence may span, plus slack
 constexpr uint32_t kSeqTyp = 320;           // a window with fewer bytes than this behind ip is not worth a parse
 constexpr uint32_t kFarMax = 320;           // bytes per match the out-of-buffer path fetches (5 steps of 64)
+#ifndef LZ4MI_PRIO_T
+#define LZ4MI_PRIO_T 12288, 8192, 4096
+#endif
+constexpr uint32_t kPrioT[3] = {LZ4MI_PRIO_T};  // compressed bytes left from which a block runs at issue priority 3, 2, 1
+constexpr uint32_t kPrio3 = kPrioT[0], kPrio2 = kPrioT[1], kPrio1 = kPrioT[2];
 constexpr uint32_t kTl = 136;               // token list entries (two bytes each): 64 tokens, a spare, the dummy slot at 128
 static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at least one sequence");
 static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
@@ -521,6 +526,17 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     bool general = true;
     PH(7);
     if (in_end - ip >= 8u) {
+#ifndef LZ4MI_NO_PRIO
+      // Longest remaining work first: the wavefronts of a SIMD compete for its issue slots, and a launch
+      // ends with its slowest block.  What is left of the compressed block stands for the work left.
+      {
+        const uint32_t left = in_end - ip;
+        if (left >= kPrio3) __builtin_amdgcn_s_setprio(3);
+        else if (left >= kPrio2) __builtin_amdgcn_s_setprio(2);
+        else if (left >= kPrio1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+      }
+#endif
       // ---- window: keep it while a typical sequence still fits behind ip, or it holds the block's end
       if (!have_win || !((ip - (uint32_t)wb) + kSeqTyp <= kCw || (uint32_t)(wb + (int32_t)kCw) >= in_end)) {
         cw_load(cw, src, in_end, ip, lane, wb, wlim);
@@ -834,6 +850,9 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     PH(6);
   }
   PH_FLUSH(g_dec_phase, lane);
+#ifndef LZ4MI_NO_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   out_len = op;
   return st;
 }
