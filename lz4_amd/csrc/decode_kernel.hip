@@ -354,7 +354,7 @@ constexpr uint32_t kDummy = kStgBytes;      // 64 + 8 bytes behind the buffer th
 constexpr uint32_t kStgAlloc = kStgBytes + 80;
 constexpr uint32_t kCw = 2048;              // compressed window in LDS
 constexpr uint32_t kCwPad = 16;
-constexpr uint32_t kCwTop = kCw + kCwPad - 8;   // highest offset an 8-byte read may start at
+constexpr uint32_t kCwTop = kCw + kCwPad - 12;  // highest offset an 8-byte read may start at (three aligned dwords from the one below it)
 constexpr uint32_t kLitMax = 15 + 6 * 255 + 254;  // longest literal run of a batched sequence (up to seven extension bytes)
 constexpr uint32_t kMatMax = 19 + 5 * 255 + 254;  // longest match (up to six extension bytes)
 constexpr uint32_t kSeqIn = 8 + kLitMax + 8 + 8;  // compressed bytes a batched sequence may span, plus slack
@@ -378,7 +378,23 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2 lds_u64v;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
-// bytes at window offset a (clamped: a read past the window returns bytes that no caller uses)
+// bytes at window offset a (clamped: a read past the window returns bytes that no caller uses).
+// An LDS access whose address is not a multiple of its size stalls the CU's LDS pipe (shared by its
+// sixteen wavefronts) for about twenty cycles, so the bytes are put together from aligned dwords
+// (scripts/micro/lds_unaligned_tp.hip: 304 against 46 cycles per read and wavefront).
+#ifndef LZ4MI_UNALIGNED_LDS
+__device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
+  a = a < kCwTop ? a : kCwTop;
+  const lds_u32 *q = (const lds_u32 *)(cw + (a & ~3u));
+  return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+}
+__device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
+  a = a < kCwTop ? a : kCwTop;
+  const lds_u32 *q = (const lds_u32 *)(cw + (a & ~3u));
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+  return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, a & 3u) << 32) | __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
+#else
 __device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
   a = a < kCwTop ? a : kCwTop;
   return ((const lds_dp32 *)(cw + a))->v;
@@ -387,6 +403,7 @@ __device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
   a = a < kCwTop ? a : kCwTop;
   return ((const lds_dp64 *)(cw + a))->v;
 }
+#endif
 
 // Parses the byte at window offset a as a token, common form: each length with at most one
 // extension byte.  nx1 = where the next token starts in that form, which is all the chain of token

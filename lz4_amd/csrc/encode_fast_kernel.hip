@@ -70,9 +70,26 @@ struct Win {
   uint32_t lo, hi;     // ring holds block offsets [lo, hi), both multiples of kSeg; bytes at or past n read as zero
 };
 
-// Ring reads by block offset (the caller guarantees residency).
+// Ring reads by block offset (the caller guarantees residency).  An LDS read whose address is not a
+// multiple of its size stalls the CU's LDS pipe for about twenty cycles (sixteen wavefronts share that
+// pipe: measured 304 cycles per unaligned ds_read_b32 per wavefront against 46 for the form below,
+// scripts/micro/lds_unaligned_tp.hip), so the bytes are put together from aligned dwords.
+#ifndef LZ4MI_UNALIGNED_LDS
+__device__ __forceinline__ uint32_t w32(const Win &w, uint32_t s) {
+  const uint32_t a = s & kWinMask;
+  const lds_u32 *q = (const lds_u32 *)(w.lds + (a & ~3u));  // q[1] may lie in the wrap mirror
+  return __builtin_amdgcn_alignbyte(q[1], q[0], a & 3u);
+}
+__device__ __forceinline__ uint64_t w64(const Win &w, uint32_t s) {
+  const uint32_t a = s & kWinMask;
+  const lds_u32 *q = (const lds_u32 *)(w.lds + (a & ~3u));
+  const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+  return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, a & 3u) << 32) | __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+}
+#else
 __device__ __forceinline__ uint32_t w32(const Win &w, uint32_t s) { return ((lds_p32 *)(w.lds + (s & kWinMask)))->v; }
 __device__ __forceinline__ uint64_t w64(const Win &w, uint32_t s) { return ((lds_p64 *)(w.lds + (s & kWinMask)))->v; }
+#endif
 __device__ __forceinline__ uint32_t w8(const Win &w, uint32_t s) { return w.lds[s & kWinMask]; }
 
 // 16 bytes per lane of the 1 KiB segment at block offset pos (zero past the end of the block).
