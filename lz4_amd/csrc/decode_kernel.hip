@@ -752,6 +752,72 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           }
           PH(2);
 
+#ifndef LZ4MI_UNALIGNED_LDS
+          // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
+          // off (that costs more than the copies) and every LDS access is aligned (an unaligned one stalls the
+          // LDS pipe of the CU): the up to three bytes in front of the first aligned dword of the destination
+          // and the up to three behind the last go byte by byte, as does a run too short to hold an aligned
+          // dword; the dwords in between are put together from the aligned dwords of the window they straddle.
+          // What does not apply writes to a dummy slot.
+          {
+            const uint32_t n = lane < nb ? ll : 0u;
+            const uint32_t lsx = lane < nb ? ls : 0u;
+            const uint32_t d0 = o_lit + sneg;
+            const uint32_t n1 = n < 64u ? n : 64u;
+            const uint32_t head = (0u - d0) & 3u;
+            const bool mid = n1 >= head + 4u;
+            const uint32_t body = mid ? (n1 - head) >> 2 : 0u;  // aligned dwords, at most 16
+            const uint32_t tail = mid ? (n1 - head) & 3u : 0u;
+            {
+              const uint32_t sb = lsx + head, sh = sb & 3u;
+              const lds_u32 *q = (const lds_u32 *)(cw + ((sb < kCwTop ? sb : kCwTop) & ~3u));
+              uint32_t wd[17];
+#pragma unroll
+              for (uint32_t k = 0; k < 17; k++) wd[k] = q[k];
+              lds_u32 *d = (lds_u32 *)(stg + d0 + head);
+              lds_u32 *dummy = (lds_u32 *)(stg + kDummy + 64u);
+#pragma unroll
+              for (uint32_t k = 0; k < 16; k++) *(k < body ? d + k : dummy) = __builtin_amdgcn_alignbyte(wd[k + 1], wd[k], sh);
+            }
+            {
+              // six single bytes: head (or the whole of a short run) from the run's first bytes, tail from its last
+              const uint64_t f8 = cw64(cw, lsx);
+              const uint32_t toff = head + 4u * body;
+              const uint32_t t4 = cw32(cw, lsx + toff);
+              const uint32_t nfirst = mid ? head : n1;  // bytes taken from the front (at most six)
+#pragma unroll
+              for (uint32_t i = 0; i < 6; i++) {
+                const bool front = i < nfirst;
+                const bool back = mid && i >= 3u && i - 3u < tail;
+                const uint32_t v = front ? (uint32_t)(f8 >> (8u * i)) : t4 >> (8u * (i - 3u < 3u ? i - 3u : 0u));
+                stg[front ? d0 + i : back ? d0 + toff + (i - 3u) : kDummy + lane] = (uint8_t)v;
+              }
+            }
+            // runs longer than 64 bytes, one after the other: bytes 56.. of the run, 256 bytes per step, the same way
+            // with the whole wavefront on one run (at least 9 bytes are left)
+            for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
+              const uint32_t j = (uint32_t)__builtin_ctzll(lm);
+              const uint32_t s0 = rdlane(lsx, j) + 56u, e0 = rdlane(d0, j) + 56u, rem = rdlane(n, j) - 56u;
+              const uint32_t hb = (0u - e0) & 3u;
+              const uint32_t bd = (rem - hb) >> 2, tl3 = (rem - hb) & 3u;
+              {
+                const bool edge = lane < hb || (lane >= 4u && lane - 4u < tl3);
+                const uint32_t eo = lane < hb ? lane : hb + 4u * bd + (lane - 4u);
+                const uint32_t v = cw[s0 + (edge ? eo : 0u)];
+                stg[edge ? e0 + eo : kDummy + lane] = (uint8_t)v;
+              }
+              const uint32_t sb = s0 + hb, sh = sb & 3u;
+              const lds_u32 *q = (const lds_u32 *)(cw + (sb & ~3u));
+              lds_u32 *d = (lds_u32 *)(stg + e0 + hb);
+              for (uint32_t k0 = 0; k0 < bd; k0 += kWave) {
+                const uint32_t k = k0 + lane;
+                const uint32_t kk = k < bd ? k : 0u;
+                const uint32_t v = __builtin_amdgcn_alignbyte(q[kk + 1u], q[kk], sh);
+                *(k < bd ? d + k : (lds_u32 *)(stg + kDummy + 64u)) = v;
+              }
+            }
+          }
+#else
           // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
           // off (that costs more than the copies): a run of 8 bytes or more goes in 8-byte pieces whose
           // offsets are clamped to length - 8, so the last pieces overlap; runs of 4..7 bytes in two
@@ -792,6 +858,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
               }
             }
           }
+#endif
           PH(3);
 
           // ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a
