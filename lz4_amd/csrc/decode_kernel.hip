@@ -370,10 +370,6 @@ static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at
 static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
 static_assert(kH % 1024 == 0, "layout");
 
-struct __attribute__((packed)) DP32 { uint32_t v; };
-struct __attribute__((packed)) DP64 { uint64_t v; };
-typedef __attribute__((address_space(3))) DP32 lds_dp32;
-typedef __attribute__((address_space(3))) DP64 lds_dp64;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) u32x2 lds_u64v;
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
@@ -382,7 +378,6 @@ typedef __attribute__((address_space(3))) uint16_t lds_u16;
 // An LDS access whose address is not a multiple of its size stalls the CU's LDS pipe (shared by its
 // sixteen wavefronts) for about twenty cycles, so the bytes are put together from aligned dwords
 // (scripts/micro/lds_unaligned_tp.hip: 304 against 46 cycles per read and wavefront).
-#ifndef LZ4MI_UNALIGNED_LDS
 __device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
   a = a < kCwTop ? a : kCwTop;
   const lds_u32 *q = (const lds_u32 *)(cw + (a & ~3u));
@@ -394,16 +389,6 @@ __device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
   const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
   return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, a & 3u) << 32) | __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
 }
-#else
-__device__ __forceinline__ uint32_t cw32(const lds_u8 *cw, uint32_t a) {
-  a = a < kCwTop ? a : kCwTop;
-  return ((const lds_dp32 *)(cw + a))->v;
-}
-__device__ __forceinline__ uint64_t cw64(const lds_u8 *cw, uint32_t a) {
-  a = a < kCwTop ? a : kCwTop;
-  return ((const lds_dp64 *)(cw + a))->v;
-}
-#endif
 
 // Parses the byte at window offset a as a token, common form: each length with at most one
 // extension byte.  nx1 = where the next token starts in that form, which is all the chain of token
@@ -752,7 +737,6 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           }
           PH(2);
 
-#ifndef LZ4MI_UNALIGNED_LDS
           // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
           // off (that costs more than the copies) and every LDS access is aligned (an unaligned one stalls the
           // LDS pipe of the CU): the up to three bytes in front of the first aligned dword of the destination
@@ -817,48 +801,6 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
               }
             }
           }
-#else
-          // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
-          // off (that costs more than the copies): a run of 8 bytes or more goes in 8-byte pieces whose
-          // offsets are clamped to length - 8, so the last pieces overlap; runs of 4..7 bytes in two
-          // overlapping dwords; shorter ones byte by byte; what does not apply writes to a dummy slot.
-          {
-            const uint32_t n = lane < nb ? ll : 0u;
-            const uint32_t d0 = o_lit + sneg;
-            {
-              const bool use8 = n >= 8u;
-              const uint32_t top = (n < 64u ? n : 64u) - 8u;
-              uint64_t wv[8];
-              uint32_t o[8];
-#pragma unroll
-              for (uint32_t k = 0; k < 8; k++) {
-                o[k] = 8u * k < top ? 8u * k : top;
-                wv[k] = cw64(cw, ls + (use8 ? o[k] : 0u));
-              }
-#pragma unroll
-              for (uint32_t k = 0; k < 8; k++) ((lds_dp64 *)(stg + (use8 ? d0 + o[k] : kDummy + 64u)))->v = wv[k];
-            }
-            {
-              const bool use4 = n >= 4u && n < 8u;
-              const uint32_t w0 = cw32(cw, ls), w1 = cw32(cw, ls + (use4 ? n - 4u : 0u));
-              ((lds_dp32 *)(stg + (use4 ? d0 : kDummy + 64u)))->v = w0;
-              ((lds_dp32 *)(stg + (use4 ? d0 + n - 4u : kDummy + 64u)))->v = w1;
-              const uint32_t b3 = cw32(cw, ls);
-#pragma unroll
-              for (uint32_t i = 0; i < 3; i++) stg[n < 4u && i < n ? d0 + i : kDummy + lane] = (uint8_t)(b3 >> (8u * i));
-            }
-            // runs longer than 64 bytes, one after the other: bytes 56.. in 8-byte pieces, 512 bytes per step,
-            // clamped the same way (at least 9 bytes are left, so a piece always fits)
-            for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
-              const uint32_t j = (uint32_t)__builtin_ctzll(lm);
-              const uint32_t s0 = rdlane(ls, j) + 56u, e0 = rdlane(d0, j) + 56u, top = rdlane(n, j) - 64u;  // len - 8
-              for (uint32_t k0 = 0; k0 < top + 8u; k0 += 8 * kWave) {  // the last step has a lane at or past `top`
-                const uint32_t o = k0 + 8u * lane < top ? k0 + 8u * lane : top;
-                ((lds_dp64 *)(stg + e0 + o))->v = cw64(cw, s0 + o);
-              }
-            }
-          }
-#endif
           PH(3);
 
           // ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a

@@ -45,8 +45,8 @@ __device__ unsigned long long g_enc_span[2 * 65536];  // per block: start and en
 // ring, one sequence costs a single vector-memory wait (the hash-table gather of its probes);
 // everything written for a sequence (output bytes, table inserts) is issued after the last
 // read of that sequence.
-// The first 16 bytes of the ring are mirrored behind its end so that an unaligned 4- or 8-byte
-// read never has to be split at the wrap.
+// The first 16 bytes of the ring are mirrored behind its end so that a 4- or 8-byte read (the
+// aligned dwords it is put together from) never has to be split at the wrap.
 #ifndef LZ4MI_WIN
 #define LZ4MI_WIN 8192
 #endif
@@ -58,10 +58,6 @@ constexpr uint32_t kClaimSlots = 256;  // LDS dwords per wavefront for the same-
 constexpr uint32_t kFirst = LZ4MI_FIRST;  // probes of a run evaluated in the first step (bench encode launch: 8 -> 2.74-2.79 ms, 9-11 -> 2.69-2.73, 16 and 4 clearly slower)
 constexpr uint32_t kLead = kFirst > 8 ? 1024 : 640;  // an iteration may read ring bytes up to anchor + kLead
 
-struct __attribute__((packed)) P32 { uint32_t v; };
-struct __attribute__((packed)) P64 { uint64_t v; };
-typedef const __attribute__((address_space(3))) P32 lds_p32;
-typedef const __attribute__((address_space(3))) P64 lds_p64;
 
 struct Win {
   lds_u8 *lds;         // this wavefront's ring (16-byte aligned, kWinBytes + kWinPad bytes)
@@ -74,7 +70,6 @@ struct Win {
 // multiple of its size stalls the CU's LDS pipe for about twenty cycles (sixteen wavefronts share that
 // pipe: measured 304 cycles per unaligned ds_read_b32 per wavefront against 46 for the form below,
 // scripts/micro/lds_unaligned_tp.hip), so the bytes are put together from aligned dwords.
-#ifndef LZ4MI_UNALIGNED_LDS
 __device__ __forceinline__ uint32_t w32(const Win &w, uint32_t s) {
   const uint32_t a = s & kWinMask;
   const lds_u32 *q = (const lds_u32 *)(w.lds + (a & ~3u));  // q[1] may lie in the wrap mirror
@@ -86,10 +81,6 @@ __device__ __forceinline__ uint64_t w64(const Win &w, uint32_t s) {
   const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
   return ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, a & 3u) << 32) | __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
 }
-#else
-__device__ __forceinline__ uint32_t w32(const Win &w, uint32_t s) { return ((lds_p32 *)(w.lds + (s & kWinMask)))->v; }
-__device__ __forceinline__ uint64_t w64(const Win &w, uint32_t s) { return ((lds_p64 *)(w.lds + (s & kWinMask)))->v; }
-#endif
 __device__ __forceinline__ uint32_t w8(const Win &w, uint32_t s) { return w.lds[s & kWinMask]; }
 
 // 16 bytes per lane of the 1 KiB segment at block offset pos (zero past the end of the block).
