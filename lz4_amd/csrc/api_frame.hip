@@ -409,10 +409,10 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   const uint64_t final_cap = plan_total < limit_total + slot ? plan_total : limit_total + slot;
 
   // per-block arrays, host (pinned) and device, same layout:
-  // fixed:    [payload_off u64][payload_len u32][raw u32][dec_len u32][cap u32]
+  // fixed:    [payload_off u64][payload_len u32][raw u32][dec_len u32][cap u32][stored_len u32]
   // per launch: [dst_off u64][copy_src u64][copy_dst u64][copy_len u32]
   // results:  [out_len u32][status i32][hash u32]
-  const size_t fixed_bytes = (size_t)nb * 24, hb = (size_t)nb * 64;
+  const size_t fixed_bytes = (size_t)nb * 28, hb = (size_t)nb * 72;  // 68 bytes per block, 8-byte aligned arrays
   int32_t st = pin_reserve(c, hb + 64);
   if (st) return st;
   uint64_t *h_poff = (uint64_t *)c->h_pin;
@@ -420,7 +420,8 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   uint32_t *h_raw = h_plen + nb;
   uint32_t *h_dlen = h_raw + nb;
   uint32_t *h_cap = h_dlen + nb;
-  uint64_t *h_doff = (uint64_t *)(h_cap + nb);
+  uint32_t *h_slen = h_cap + nb;
+  uint64_t *h_doff = (uint64_t *)(((uintptr_t)(h_slen + nb) + 7) & ~(uintptr_t)7);
   uint64_t *h_csrc = h_doff + nb;
   uint64_t *h_cdst = h_csrc + nb;
   uint32_t *h_clen = (uint32_t *)(h_cdst + nb);
@@ -433,7 +434,8 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   uint32_t *d_raw = d_plen + nb;
   uint32_t *d_dlen = d_raw + nb;
   uint32_t *d_cap = d_dlen + nb;
-  uint64_t *d_doff = (uint64_t *)(d_cap + nb);
+  uint32_t *d_slen = d_cap + nb;
+  uint64_t *d_doff = (uint64_t *)(((uintptr_t)(d_slen + nb) + 7) & ~(uintptr_t)7);
   uint64_t *d_csrc = d_doff + nb;
   uint64_t *d_cdst = d_csrc + nb;
   uint32_t *d_clen = (uint32_t *)(d_cdst + nb);
@@ -448,6 +450,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     h_raw[b] = blocks[b].raw;
     h_dlen[b] = (blocks[b].raw && indep) ? 0u : blocks[b].size;  // a stored block decodes to nothing: it is copied
     h_cap[b] = (uint32_t)decoded_bound(blocks[b].size, slot);    // tmp ByteWriter(maxLength: blockMaxSize) :292
+    h_slen[b] = (blocks[b].raw && indep) ? blocks[b].size : 0u;    // copied by the decode launch
     any_ck |= blocks[b].has_ck != 0;
   }
   LZ4MI_HIP(c, hipMemcpyAsync(d_poff, h_poff, fixed_bytes, hipMemcpyHostToDevice, c->stream));
@@ -518,17 +521,11 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
       const uint64_t left = limit_total > produced ? limit_total - produced : 0;
       const uint64_t room = left + slot < budget ? left + slot : budget;
       uint64_t run = 0;
-      uint32_t b1 = b0, nraw = 0;
+      uint32_t b1 = b0;
       while (b1 < nb) {
         const uint64_t need = round_up((size_t)planned_output(blocks[b1], slot), 16);
         if (b1 > b0 && run + need > room) break;
         h_doff[b1] = run;
-        if (blocks[b1].raw) {  // stored blocks are plain copies into their slots
-          h_csrc[nraw] = (uint64_t)(uintptr_t)(c->in.as<uint8_t>() + blocks[b1].payload_off);
-          h_cdst[nraw] = run;
-          h_clen[nraw] = blocks[b1].size;
-          nraw++;
-        }
         run += need;
         b1++;
       }
@@ -549,14 +546,9 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
       a.nblocks = n;
       a.out_len = d_olen + b0;
       a.status = d_stat + b0;
+      a.stored_len = d_slen + b0;  // stored blocks are plain copies into their slots, in the same launch
       st = run_decompress(c, a, false);
       if (st) return st;
-      if (nraw) {
-        LZ4MI_HIP(c, hipMemcpyAsync(d_csrc, h_csrc, (size_t)nraw * 8, hipMemcpyHostToDevice, c->stream));
-        LZ4MI_HIP(c, hipMemcpyAsync(d_cdst, h_cdst, (size_t)nraw * 8, hipMemcpyHostToDevice, c->stream));
-        LZ4MI_HIP(c, hipMemcpyAsync(d_clen, h_clen, (size_t)nraw * 4, hipMemcpyHostToDevice, c->stream));
-        launch_seg_copy(d_csrc, d_slots, d_cdst, 0, d_clen, nraw, c->stream);
-      }
       LZ4MI_HIP(c, hipGetLastError());
       LZ4MI_HIP(c, hipMemcpyAsync(h_olen + b0, d_olen + b0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
       LZ4MI_HIP(c, hipMemcpyAsync(h_stat + b0, d_stat + b0, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
@@ -829,9 +821,9 @@ extern "C" int32_t lz4mi_frame_shard_decode(lz4mi_ctx *c, const uint8_t *d_recor
   a.nblocks = nblocks;
   a.out_len = d_out_len;
   a.status = d_status;
+  a.stored_len = r.raw_len;  // stored blocks (:268-271) are copied by the same launch
   int32_t st = run_decompress(c, a, false);
   if (st) return st;
-  launch_seg_copy(r.payload_addr, d_dst, r.slot_off, 0, r.raw_len, nblocks, c->stream);  // stored blocks (:268-271)
   if (o->block_checksum) {
     BatchArgs h;
     memset(&h, 0, sizeof h);

@@ -914,8 +914,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int32_t st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg,
-                                                        cw, tl, lane, out_len);
+    int32_t st = LZ4MI_OK;
+    const uint32_t stored = a.stored_len ? uni(a.stored_len[b]) : 0u;
+    if (stored) {  // a stored block rides in the same queue: its copy overlaps the issue-bound blocks
+      wave_copy(dst, src, stored, lane);
+      vm_quiesce();
+      out_len = stored;
+    } else {
+      st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg, cw, tl, lane,
+                                            out_len);
+    }
 #ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1004,7 +1012,7 @@ __global__ __launch_bounds__(256) void decode_order_count_kernel(BatchArgs a, ui
   bool heavy = false;
   if (valid) {
     const uint64_t c = block_src_len(a, b), n = a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform;
-    heavy = c * 16 < n * 15 && c * 32 > n;
+    heavy = c * 16 < n * 15 && c * 32 > n && !(a.stored_len && a.stored_len[b]);
   }
   const uint64_t hm = ballot(heavy), lm = ballot(valid && !heavy);
   uint32_t bh = 0, bl = 0;

@@ -30,6 +30,9 @@ struct BatchArgs {
   // Nonzero: blocks follow the lz4 block format's end-of-block rules instead of the reference's
   // (which ends blocks inside matches): see EncIn::plimit / elimit.
   uint32_t conformant = 0;
+  // Decoder only: per block, nonzero = the block is stored (a frame record with bit 31 set,
+  // lz4_frame_decoder.dart:268-271): that many source bytes are copied instead of decoded.
+  const uint32_t *stored_len = nullptr;
 };
 
 __host__ __device__ inline uint32_t block_src_len(const BatchArgs &a, uint32_t b) {
