@@ -579,15 +579,19 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
           const bool isl = ll0 == 15u;
           const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
-          const uint64_t okm = ballot(a + nx <= wlim && !(isl && e1 == 255u));
+          // where the token behind this one starts; a token that is not for the chain (or not inside the window)
+          // points past every lane and carries its own lane, so the walk is one cross-lane read and one test per token
+          const uint32_t link = (a + nx <= wlim && !(isl && e1 == 255u)) ? nx : 0x8000u | lane;
           uint64_t starts = 0;
           uint32_t r = 0;
-          bool notok = false;
-          for (;;) {
-            if (!((okm >> r) & 1ull)) { notok = true; break; }
+          do {
             starts |= 1ull << r;
-            r = rdlane(nx, r);
-            if (r >= kWave) break;
+            r = rdlane(link, r);
+          } while (r < kWave);
+          const bool notok = (r & 0x8000u) != 0u;
+          if (notok) {  // the chain ends in front of that token
+            r &= 0x7fffu;
+            starts &= ~(1ull << r);
           }
           tl[(starts >> lane) & 1ull ? count + mbcnt64(starts) : 2u * kWave] = (uint16_t)(a + lane);
           const uint32_t n = (uint32_t)__builtin_popcountll(starts);
@@ -684,12 +688,17 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         far = far && lane < nb;
         const bool near = lane < nb && !far;
         // match descriptors: source and destination as buffer offsets; length (0: nothing to do here) and distance
-        const uint32_t vA = (((uint32_t)sp + sneg) & 0xffffu) | ((o_mat + sneg) << 16);
-        const uint32_t vB = (near ? ml : 0u) | (dist << 16);
-        // lane mod dist without a division in the copy loop: q = (lane * mg) >> 16 is lane / dist for lane < 64
-        // (mg = 65536 / dist + 1 is off by less than 1 / dist over that range); step = 64 mod dist
+        // Every value the copy loop needs sits in a register of its own, ready for one cross-lane read: the loop
+        // runs once per match on the scalar unit, which the wavefronts of a CU share, and unpacking there costs
+        // more than the extra reads.  An overlapping match (byte_writer.dart:116-118) repeats its period:
+        // lane mod dist without a division is lane - ((lane * mg) >> 16) * dist with mg = 65536 / dist + 1
+        // (off by less than 1 / dist for lane < 64), and a piece of 64 bytes moves on by 64 mod dist.  A plain
+        // copy has mg = 0 (lane mod dist = lane where it matters), step 64 and a period it never reaches.
+        const bool ovl = dist < ml;
         const uint32_t dsafe = dist ? dist : 1u;
-        const uint32_t vC = (65536u / dsafe + 1u) | ((64u % dsafe) << 17);
+        const uint32_t m_src = ((uint32_t)sp + sneg) & 0xffffu, m_dst = o_mat + sneg;
+        const uint32_t m_len = near ? ml : 0u, m_per = ovl ? dist : 0xffffu;
+        const uint32_t m_mg = ovl ? 65536u / dsafe + 1u : 0u, m_step = ovl ? 64u % dsafe : kWave;
         PH(1);
         if (nb) {
 #ifdef LZ4MI_PROFILE
@@ -808,14 +817,11 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
           // byte by byte: output byte k is byte k mod dist of the period in front of the match.
           // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
           for (uint32_t j = 0; j < nb; j++) {
-            const uint32_t B = rdlane(vB, j);
-            const uint32_t m = B & 0xffffu;
+            const uint32_t m = rdlane(m_len, j);
             if (!m) continue;
-            const uint32_t d = B >> 16, A = rdlane(vA, j), C = rdlane(vC, j);
-            const uint32_t ms = A & 0xffffu, md = (A >> 16) + lane;
-            const uint32_t per = d < m ? d : 0x40000000u;  // a plain copy never reaches its period
-            const uint32_t step = d < m ? C >> 17 : kWave;
-            uint32_t r = lane - __umul24(__umul24(lane, C & 0x1ffffu) >> 16, d);  // lane mod d
+            const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
+            const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
+            uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
             for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
               const uint32_t v = stg[ms + r];
               stg[k0 + lane < m ? md + k0 : kDummy + lane] = (uint8_t)v;
