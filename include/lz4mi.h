@@ -192,6 +192,15 @@ int32_t lz4mi_decompress_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t str
 #define LZ4MI_STATIC_MAX_BLOCKS (1u << 20)
 int32_t lz4mi_decompress_batch_static(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t strict);
 
+/* How a decode launch spreads its blocks.  No counterpart in the reference (a tuning knob of this
+ * library; results never depend on it).  0 (default): by launch size - launches that leave wavefront
+ * slots empty give every block a workgroup of two wavefronts (one finds the sequences and places the
+ * literals of the next batch while the other copies the matches of the current one: a block is done in
+ * 0.6 of the time), larger launches give every block one wavefront (twice as many blocks in flight).
+ * 1: always one wavefront per block.  2: always two.  Process-wide; returns the previous setting, or
+ * -1 for a value out of range.  The environment variable LZ4MI_DEC_FORM=single|pair sets the start value. */
+int32_t lz4mi_set_decode_form(int32_t form);
+
 /* xxh32 of each block's source bytes (seed 0): block checksums
  * (lib/src/frame/lz4_frame_encoder.dart:242-257, lz4_frame_decoder.dart:257-266).
  * Only d_src/d_src_off/d_src_len/src_* /nblocks are read; d_hash receives nblocks words. */

@@ -288,6 +288,11 @@ extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, in
   return run_decompress(c, a, strict != 0);
 }
 
+extern "C" int32_t lz4mi_set_decode_form(int32_t form) {
+  if (form < 0 || form > 2) return -1;
+  return set_decode_form(form);
+}
+
 extern "C" int32_t lz4mi_decompress_batch_static(lz4mi_ctx *c, const lz4mi_batch *b, int32_t strict) {
   if (!c || !b) return LZ4MI_RANGE;
   LZ4MI_HIP(c, ::lz4mi::enter_device(c));

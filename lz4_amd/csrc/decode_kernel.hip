@@ -21,6 +21,9 @@
 //
 // The general loop (decode_run) takes such a sequence on its own, straight from and to memory,
 // in the reference's order of checks, and is where every block ends: all status codes come from it.
+#include <atomic>
+#include <cstdlib>
+
 #include "device_common.h"
 #include "kernels.h"
 #include "profile.h"
@@ -28,7 +31,7 @@
 namespace lz4mi {
 
 #ifdef LZ4MI_PROFILE
-__device__ unsigned long long g_dec_phase[PH_SLOTS];
+__device__ unsigned long long g_dec_phase[2 * PH_SLOTS];  // parsing wavefront, copying wavefront
 #endif
 #if defined(LZ4MI_PROFILE) || defined(LZ4MI_SPANS)
 #define LZ4MI_DEC_SPANS 1
@@ -182,6 +185,46 @@ __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t d
   vm_quiesce();
 }
 
+// State the two wavefronts of a block share (decode_block_pair).
+struct PairShared {
+  uint32_t hdr[2][4];        // per descriptor slot: sequences, output position behind the batch, compressed position, general-loop flag
+  uint32_t desc[2][4][kWave];  // per slot and lane: match source position, match output position, length | far << 31, distance
+  uint32_t ctl[8];           // behind the general loop: ip, op, fl, sneg, vlo, status, done
+  uint32_t req[6];           // general loop: a copy for both wavefronts (kind, destination, source, length) or its end
+  uint32_t next;             // next block of the queue
+};
+typedef __attribute__((address_space(3))) PairShared lds_pair;
+constexpr uint32_t kReqCopy = 1, kReqEnd = 2;
+constexpr uint32_t kPairCopyMin = 1024;  // literal runs from this length on are copied by both wavefronts
+
+// The copying wavefront, inside the general loop, has a long copy: the parsing wavefront (waiting in
+// pair_serve) takes the first part.  Both have left the copy behind when this returns.
+__device__ __forceinline__ void pair_copy(lds_pair *sh, uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
+  uint32_t h = n / 2u;
+  h -= (uint32_t)((uintptr_t)dst + h) & 15u;  // the second part starts on a 16-byte boundary
+  if (lane < 6) {
+    const uint64_t d = (uint64_t)(uintptr_t)dst, g = (uint64_t)(uintptr_t)src;
+    sh->req[lane] = lane == 0 ? kReqCopy : lane == 1 ? (uint32_t)d : lane == 2 ? (uint32_t)(d >> 32) : lane == 3 ? (uint32_t)g
+                    : lane == 4 ? (uint32_t)(g >> 32) : h;
+  }
+  __syncthreads();
+  wave_copy(dst + h, src + h, n - h, lane);
+  vm_quiesce();
+  __syncthreads();
+}
+// The parsing wavefront while the general loop runs on the other one: serves its copies until the end is signalled.
+__device__ __forceinline__ void pair_serve(lds_pair *sh, uint32_t lane) {
+  for (;;) {
+    __syncthreads();
+    if (uni(sh->req[0]) == kReqEnd) break;
+    uint8_t *dst = (uint8_t *)(uintptr_t)(((uint64_t)uni(sh->req[2]) << 32) | uni(sh->req[1]));
+    const uint8_t *src = (const uint8_t *)(uintptr_t)(((uint64_t)uni(sh->req[4]) << 32) | uni(sh->req[3]));
+    wave_copy(dst, src, uni(sh->req[5]), lane);
+    vm_quiesce();
+    __syncthreads();
+  }
+}
+
 constexpr uint32_t kRing = 4096;   // bytes of recent output the general loop mirrors in LDS
 constexpr uint32_t kShort = 256;   // copies up to this length go through its ring path
 
@@ -194,11 +237,12 @@ constexpr uint32_t kShort = 256;   // copies up to this length go through its ri
 // were a block of its own.  With ONE it returns kSwitchRun after one complete sequence (literals
 // and match); in_used / out_len say how far it got.
 constexpr int32_t kSwitchRun = -1;  // not a status: the block goes on at in_used / out_len
-template <bool STRICT, bool HAS_PREFIX, bool ONE>
+template <bool STRICT, bool HAS_PREFIX, bool ONE, bool PAIR = false>
 __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                               const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                               const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                              lds_u8 *ring, uint32_t lane, uint32_t &in_used, uint32_t &out_len) {
+                                              lds_u8 *ring, uint32_t lane, uint32_t &in_used, uint32_t &out_len,
+                                              lds_pair *sh = nullptr) {
   InWindow w;
   w.mis = (uint32_t)((uintptr_t)src & 3u);
   w.al = src - w.mis;
@@ -262,8 +306,12 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         sm.S = v;
         if (op + lit > rlo + kRing) rlo = op + lit - kRing;
       } else {
-        wave_copy(out + op, src + ip, lit, lane);
-        vm_quiesce();
+        if (PAIR && lit >= kPairCopyMin) {
+          pair_copy(sh, out + op, src + ip, lit, lane);
+        } else {
+          wave_copy(out + op, src + ip, lit, lane);
+          vm_quiesce();
+        }
         rlo = op + lit;  // ring holds nothing older than this
       }
       ip += lit;
@@ -349,9 +397,10 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 #endif
 constexpr uint32_t kH = LZ4MI_HIST;         // output bytes kept in LDS in front of a batch (multiple of 1024)
 constexpr uint32_t kBatchOut = LZ4MI_BATCH; // most output bytes of one batch
-constexpr uint32_t kStgBytes = kH + 16 + kBatchOut + 16;  // staging buffer: history, alignment slack, batch, store slack
-constexpr uint32_t kDummy = kStgBytes;      // 64 + 8 bytes behind the buffer that lanes with nothing to write write to
-constexpr uint32_t kStgAlloc = kStgBytes + 80;
+constexpr uint32_t kStgBytes = kH + 16 + kBatchOut + 16;  // staging buffer of a wavefront on its own: history, alignment slack, batch, store slack
+constexpr uint32_t kStgPair = kStgBytes + kBatchOut;      // of a pair of wavefronts: the batch being copied and the one being placed
+// 64 + 8 bytes behind the buffer (offset D = its size in the copy functions) take what lanes with nothing to write write
+constexpr uint32_t kStgAlloc = kStgBytes + 80, kStgPairAlloc = kStgPair + 80;
 constexpr uint32_t kCw = 2048;              // compressed window in LDS
 constexpr uint32_t kCwPad = 16;
 constexpr uint32_t kCwTop = kCw + kCwPad - 12;  // highest offset an 8-byte read may start at (three aligned dwords from the one below it)
@@ -504,6 +553,388 @@ __device__ __forceinline__ uint32_t stg_flush(const lds_u8 *stg, uint8_t *out, u
   return from;
 }
 
+// Where stg_flush(.., all = false) stops: the flushed-up-to position after positions [from, to) were offered.
+__device__ __forceinline__ uint32_t flush_end(uint32_t sneg, uint32_t from, uint32_t to) {
+  if (from >= to) return from;
+  const uint32_t head = (0u - (from + sneg)) & 15u;
+  if (head) from += head < to - from ? head : to - from;
+  return from + ((to - from) & ~15u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A batch, in pieces.  parse_batch finds it (token chain, lane j reads sequence j, the reference's checks);
+// copy_literals, copy_far, copy_matches and stg_flush move its bytes.  One wavefront may run all of them in
+// turn (decode_block) or two may share them (decode_block_pair).
+struct ParseCtx {      // what the parsing side keeps between batches
+  int32_t wb;          // compressed offset of window byte 0 (may be negative by up to 15)
+  uint32_t wlim;       // valid bytes in the window
+  bool have_win;
+  bool dense;          // token chain: tokens are close together (chunk steps) or far apart (scalar steps)
+  uint32_t shortrun;   // scalar steps in a row that were short
+};
+struct BatchPlan {     // wave-uniform
+  uint32_t nb;         // sequences the batch takes
+  uint32_t b1;         // output position behind them
+  uint32_t ip_stop;    // compressed position behind them
+  bool general;        // what follows goes through the general loop
+};
+struct SeqLane {       // lane j: sequence j
+  uint32_t ls, ll, o_lit;     // literals: window offset, length (0 at or past nb), output position
+  int32_t sp;                 // match: source position (may lie in front of the block)
+  uint32_t o_mat, ml, dist;   //        output position, length, distance
+  bool far;                   //        source older than the buffer: fetched from memory
+};
+
+// lo = lowest output position the buffer holds when the batch is copied, fl = output in front of this
+// position is in memory by then.
+__device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src, uint32_t in_end, uint32_t ip, uint32_t op,
+                                                 uint32_t cap, uint32_t back_limit, int32_t lo, uint32_t fl, lds_u8 *cw,
+                                                 lds_u16 *tl, uint32_t lane, ParseCtx &pc, SeqLane &q) {
+  // ---- window: keep it while a typical sequence still fits behind ip, or it holds the block's end
+  if (!pc.have_win || !((ip - (uint32_t)pc.wb) + kSeqTyp <= kCw || (uint32_t)(pc.wb + (int32_t)kCw) >= in_end)) {
+    cw_load(cw, src, in_end, ip, lane, pc.wb, pc.wlim);
+    pc.have_win = true;
+  }
+  const int32_t wb = pc.wb;
+  const uint32_t wlim = pc.wlim;
+  // ---- chain of token starts.  Only where the tokens are is found here, under the assumption that no
+  // match length has a second extension byte; the positions go into a list, lane j then reads sequence j
+  // in full, and a sequence whose real successor is not the next position of the list ends the batch.
+  // Two ways to step: where tokens are dense, lane p of a 64-byte chunk parses byte a + p as a token
+  // and the real starts are followed with one cross-lane read each; where literal runs are long (one
+  // token per chunk), the token is read into scalar registers and parsed there.
+  uint32_t a = ip - (uint32_t)wb, count = 0, tot = 0;
+  bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
+  bool dense = pc.dense;
+  uint32_t shortrun = pc.shortrun;
+  while (count < kWave && tot <= kBatchOut - 512u) {
+    if (dense && count <= kWave - 22u) {
+      const uint32_t t4 = cw32(cw, a + lane);
+      const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
+      const bool isl = ll0 == 15u;
+      const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
+      // where the token behind this one starts; a token that is not for the chain (or not inside the window)
+      // points past every lane and carries its own lane, so the walk is one cross-lane read and one test per token
+      const uint32_t link = (a + nx <= wlim && !(isl && e1 == 255u)) ? nx : 0x8000u | lane;
+      uint64_t starts = 0;
+      uint32_t r = 0;
+      do {
+        starts |= 1ull << r;
+        r = rdlane(link, r);
+      } while (r < kWave);
+      const bool notok = (r & 0x8000u) != 0u;
+      if (notok) {  // the chain ends in front of that token
+        r &= 0x7fffu;
+        starts &= ~(1ull << r);
+      }
+      tl[(starts >> lane) & 1ull ? count + mbcnt64(starts) : 2u * kWave] = (uint16_t)(a + lane);
+      const uint32_t n = (uint32_t)__builtin_popcountll(starts);
+      count += n;
+      tot += r + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
+      a += r;
+      dense = n >= 2u && !notok;
+      continue;
+    }
+    // one token, in scalar registers
+    if (a + 4u > wlim) { stopped = true; break; }
+    const uint64_t t8v = cw64(cw, a);
+    const uint32_t lo32 = uni((uint32_t)t8v), hi32 = uni((uint32_t)(t8v >> 32));
+    const uint32_t ll0 = (lo32 >> 4) & 15u;
+    uint32_t ll = ll0, xl = 0;
+    if (ll0 == 15u) {
+      const uint32_t e1 = (lo32 >> 8) & 255u;
+      ll = 15u + e1;
+      xl = 1;
+      if (e1 == 255u) {  // up to seven extension bytes
+        const uint64_t ext = (((uint64_t)hi32 << 32) | lo32) >> 8;
+        const uint32_t nff = ff_bytes(ext);
+        if (nff == 7u) { stopped = true; break; }
+        ll = 15u + 255u * nff + ((uint32_t)(ext >> (8u * nff)) & 255u);
+        xl = nff + 1u;
+      }
+    }
+    const uint32_t nx = a + 1u + xl + ll + 2u + ((lo32 & 15u) == 15u ? 1u : 0u);
+    if (nx > wlim) { stopped = true; break; }
+    tl[count] = (uint16_t)a;
+    count++;
+    tot += ll + 64u;
+    shortrun = nx - a < 24u ? shortrun + 1u : 0u;
+    dense = shortrun >= 2u;
+    a = nx;
+  }
+  pc.dense = dense;
+  pc.shortrun = shortrun;
+  BatchPlan bp;
+  bp.nb = 0;
+  bp.b1 = op;
+  bp.ip_stop = (uint32_t)wb + a;
+  // A token that ends the chain: too many extension bytes, the end of the block, or the end of the window.
+  // A window that was loaded at this token holds any sequence the batch takes, so there it is not the window.
+  bp.general = stopped && ((uint32_t)(wb + (int32_t)kCw) >= in_end || a < 16u);
+  if (stopped && !bp.general) pc.have_win = false;
+  q.ls = 0; q.ll = 0; q.o_lit = op; q.sp = 0; q.o_mat = op; q.ml = 0; q.dist = 1; q.far = false;
+  if (!count) return bp;
+
+  // ---- lane j owns sequence j
+  const bool mine = lane < count;
+  const uint32_t ta = tl[lane], tn = tl[lane + 1u];
+  const SeqFields g = seq_long(cw, ta, wlim);
+  const uint32_t ll = mine ? g.ll : 0u, ml = mine ? g.ml : 0u, dist = g.dist;
+  // the sequences in front of the first one that is not for the batch, or whose successor is not the
+  // next token of the list, are real
+  const uint64_t nokm = ballot(mine && !g.ok), brkm = ballot(mine && lane + 1u < count && g.nx != tn);
+  const uint32_t nnok = nokm ? (uint32_t)__builtin_ctzll(nokm) : kWave;
+  const uint32_t nbrk = brkm ? (uint32_t)__builtin_ctzll(brkm) + 1u : kWave;
+  const uint32_t nreal = nnok < nbrk ? (nnok < count ? nnok : count) : (nbrk < count ? nbrk : count);
+  const uint32_t incl = wave_incl_scan(ll + ml);
+  const uint32_t o_lit = op + incl - (ll + ml);  // where the literals go
+  const uint32_t o_mat = o_lit + ll;             // where the match goes
+  // lz4_block_decoder.dart:33-35,61-63 and byte_writer.dart:97-104: a sequence that would fail
+  // any of them is left to the general loop, which names the failure
+  const bool good = incl <= cap - op && dist != 0u && (uint64_t)dist <= (uint64_t)o_mat + back_limit;
+  const int32_t sp = (int32_t)o_mat - (int32_t)dist;  // match source (may lie in front of the block)
+  bool far = mine && sp < lo;
+  // an out-of-buffer source that is longer than the fetch takes, or that reaches into output
+  // not yet in memory (possible right after the general loop): general loop
+  const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
+  const uint64_t realm = nreal < kWave ? (1ull << nreal) - 1ull : ~0ull;
+  const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > kBatchOut) & realm;
+  const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
+  const uint32_t nover = overm ? (uint32_t)__builtin_ctzll(overm) : kWave;
+  uint32_t nb = nreal;
+  if (nbad < nb || nover < nb) {  // a sequence that fails a check, or the batch is full
+    nb = nbad < nover ? nbad : nover;
+    bp.general = nbad <= nover;
+    pc.have_win = true;
+    bp.ip_stop = (uint32_t)wb + rdlane(ta, nb);
+  } else if (nreal < count && nnok <= nbrk) {  // a token that is not for the batch
+    const uint32_t at = rdlane(ta, nreal);
+    bp.ip_stop = (uint32_t)wb + at;
+    bp.general = (uint32_t)(wb + (int32_t)kCw) >= in_end || at < 16u;
+    pc.have_win = bp.general;
+  } else {
+    // the chain went on behind a match with more extension bytes than it assumed (then the rest of the list
+    // is void), or the list is used up: go on at the real successor of the last sequence taken
+    const uint32_t nxl = rdlane(g.nx, nb - 1u);
+    if (nreal < count || nxl != a) {
+      bp.general = false;
+      pc.have_win = true;
+    }
+    bp.ip_stop = (uint32_t)wb + nxl;
+  }
+  bp.nb = nb;
+  bp.b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
+  const bool in = lane < nb;
+  q.ls = in ? g.ls : 0u;
+  q.ll = in ? ll : 0u;
+  q.o_lit = o_lit;
+  q.sp = sp;
+  q.o_mat = o_mat;
+  q.ml = in ? ml : 0u;
+  q.dist = dist ? dist : 1u;
+  q.far = far && in;
+  return bp;
+}
+
+// ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
+// off (that costs more than the copies) and every LDS access is aligned (an unaligned one stalls the
+// LDS pipe of the CU): the up to three bytes in front of the first aligned dword of the destination
+// and the up to three behind the last go byte by byte, as does a run too short to hold an aligned
+// dword; the dwords in between are put together from the aligned dwords of the window they straddle.
+// What does not apply writes to a dummy slot.
+template <uint32_t D>
+__device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uint32_t sneg, const SeqLane &q, uint32_t lane) {
+  const uint32_t n = q.ll;
+  const uint32_t lsx = q.ls;
+  const uint32_t d0 = q.o_lit + sneg;
+  const uint32_t n1 = n < 64u ? n : 64u;
+  const uint32_t head = (0u - d0) & 3u;
+  const bool mid = n1 >= head + 4u;
+  const uint32_t body = mid ? (n1 - head) >> 2 : 0u;  // aligned dwords, at most 16
+  const uint32_t tail = mid ? (n1 - head) & 3u : 0u;
+  {
+    const uint32_t sb = lsx + head, sh = sb & 3u;
+    const lds_u32 *p = (const lds_u32 *)(cw + ((sb < kCwTop ? sb : kCwTop) & ~3u));
+    uint32_t wd[17];
+#pragma unroll
+    for (uint32_t k = 0; k < 17; k++) wd[k] = p[k];
+    lds_u32 *d = (lds_u32 *)(stg + d0 + head);
+    lds_u32 *dummy = (lds_u32 *)(stg + D + 64u);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) *(k < body ? d + k : dummy) = __builtin_amdgcn_alignbyte(wd[k + 1], wd[k], sh);
+  }
+  {
+    // six single bytes: head (or the whole of a short run) from the run's first bytes, tail from its last
+    const uint64_t f8 = cw64(cw, lsx);
+    const uint32_t toff = head + 4u * body;
+    const uint32_t t4 = cw32(cw, lsx + toff);
+    const uint32_t nfirst = mid ? head : n1;  // bytes taken from the front (at most six)
+#pragma unroll
+    for (uint32_t i = 0; i < 6; i++) {
+      const bool front = i < nfirst;
+      const bool back = mid && i >= 3u && i - 3u < tail;
+      const uint32_t v = front ? (uint32_t)(f8 >> (8u * i)) : t4 >> (8u * (i - 3u < 3u ? i - 3u : 0u));
+      stg[front ? d0 + i : back ? d0 + toff + (i - 3u) : D + lane] = (uint8_t)v;
+    }
+  }
+  // runs longer than 64 bytes, one after the other: bytes 56.. of the run, 256 bytes per step, the same way
+  // with the whole wavefront on one run (at least 9 bytes are left)
+  for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
+    const uint32_t j = (uint32_t)__builtin_ctzll(lm);
+    const uint32_t s0 = rdlane(lsx, j) + 56u, e0 = rdlane(d0, j) + 56u, rem = rdlane(n, j) - 56u;
+    const uint32_t hb = (0u - e0) & 3u;
+    const uint32_t bd = (rem - hb) >> 2, tl3 = (rem - hb) & 3u;
+    {
+      const bool edge = lane < hb || (lane >= 4u && lane - 4u < tl3);
+      const uint32_t eo = lane < hb ? lane : hb + 4u * bd + (lane - 4u);
+      const uint32_t v = cw[s0 + (edge ? eo : 0u)];
+      stg[edge ? e0 + eo : D + lane] = (uint8_t)v;
+    }
+    const uint32_t sb = s0 + hb, sh = sb & 3u;
+    const lds_u32 *p = (const lds_u32 *)(cw + (sb & ~3u));
+    lds_u32 *d = (lds_u32 *)(stg + e0 + hb);
+    for (uint32_t k0 = 0; k0 < bd; k0 += kWave) {
+      const uint32_t k = k0 + lane;
+      const uint32_t kk = k < bd ? k : 0u;
+      const uint32_t v = __builtin_amdgcn_alignbyte(p[kk + 1u], p[kk], sh);
+      *(k < bd ? d + k : (lds_u32 *)(stg + D + 64u)) = v;
+    }
+  }
+}
+
+// ---- matches whose source is older than the buffer: fetched from memory, four per round trip
+template <bool HAS_PREFIX, uint32_t D>
+__device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
+                                         uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
+  for (uint64_t fm = ballot(q.far); fm;) {
+    int32_t fs[4];
+    uint32_t fd[4], fn[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      fs[u] = 0; fd[u] = 0; fn[u] = 0;
+      if (fm) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(fm);
+        fm &= fm - 1ull;
+        fs[u] = (int32_t)rdlane((uint32_t)q.sp, j);
+        fd[u] = rdlane(q.o_mat, j) + sneg;
+        fn[u] = rdlane(q.ml, j);
+      }
+    }
+    uint32_t v[4][kFarMax / kWave];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+      for (uint32_t t = 0; t < kFarMax / kWave; t++) {
+        v[u][t] = 0;
+        if (t * kWave < fn[u]) {  // lanes past the end read the last byte again
+          const uint32_t idx = t * kWave + lane < fn[u] ? t * kWave + lane : fn[u] - 1u;
+          const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
+          v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+#pragma unroll
+      for (uint32_t t = 0; t < kFarMax / kWave; t++) {
+        if (t * kWave < fn[u]) {
+          const uint32_t idx = t * kWave + lane;
+          stg[idx < fn[u] ? fd[u] + idx : D + lane] = (uint8_t)v[u][t];
+        }
+      }
+    }
+    vm_quiesce();
+  }
+}
+
+// ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a
+// match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
+// byte by byte: output byte k is byte k mod dist of the period in front of the match.
+// A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
+template <uint32_t D>
+__device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_t nb, const SeqLane &q, uint32_t lane) {
+  // Every value the copy loop needs sits in a register of its own, ready for one cross-lane read: the loop
+  // runs once per match on the scalar unit, which the wavefronts of a CU share, and unpacking there costs
+  // more than the extra reads.  An overlapping match repeats its period: lane mod dist without a division
+  // is lane - ((lane * mg) >> 16) * dist with mg = 65536 / dist + 1 (off by less than 1 / dist for lane < 64),
+  // and a piece of 64 bytes moves on by 64 mod dist.  A plain copy has mg = 0 (lane mod dist = lane where
+  // it matters), step 64 and a period it never reaches.
+  const bool ovl = q.dist < q.ml;
+  const uint32_t m_src = ((uint32_t)q.sp + sneg) & 0xffffu, m_dst = q.o_mat + sneg;
+  const uint32_t m_len = q.far ? 0u : q.ml, m_per = ovl ? q.dist : 0xffffu;
+  const uint32_t m_mg = ovl ? 65536u / q.dist + 1u : 0u, m_step = ovl ? 64u % q.dist : kWave;
+  for (uint32_t j = 0; j < nb; j++) {
+    const uint32_t m = rdlane(m_len, j);
+    if (!m) continue;
+    const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
+    const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
+    uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
+    for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
+      const uint32_t v = stg[ms + r];
+      stg[k0 + lane < m ? md + k0 : D + lane] = (uint8_t)v;
+      r += step;
+      r = r >= per ? r - per : r;
+    }
+  }
+}
+
+// Moves the buffer down by `shift` (a multiple of 16): `bytes` bytes from offset shift on.
+__device__ __forceinline__ void stg_slide(lds_u8 *stg, uint32_t shift, uint32_t bytes, uint32_t lane) {
+  const uint32_t pieces = (bytes + 15u) >> 4;
+  for (uint32_t c0 = 0; c0 < pieces; c0 += 4 * kWave) {
+    u32x4 v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {  // lanes past the end move the last piece again
+      const uint32_t c = c0 + u * kWave + lane;
+      v[u] = *(const lds_u128 *)(stg + shift + 16u * (c < pieces ? c : pieces - 1u));
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; u++) {
+      const uint32_t c = c0 + u * kWave + lane;
+      *(lds_u128 *)(stg + 16u * (c < pieces ? c : pieces - 1u)) = v[u];
+    }
+  }
+}
+
+// Behind the general loop (which used the buffer for itself): brings back the history, kH bytes of this
+// block's output in whole aligned 16-byte pieces, under the layout sneg.  Returns the lowest position held.
+__device__ __forceinline__ int32_t stg_restore(lds_u8 *stg, uint8_t *out, uint32_t op, uint32_t sneg, uint32_t lane) {
+  // piece c holds positions [16c - sneg, 16c - sneg + 16); the last piece that holds a byte of output is
+  // the one of position op - 1
+  const uint32_t last = (op - 1u + sneg) >> 4;  // <= kH / 16
+  // lowest piece that lies inside the block's output
+  const int32_t sn = (int32_t)sneg;
+  const uint32_t cmin = sn > 0 ? (uint32_t)(sn + 15) >> 4 : 0u;
+  static_assert(kH == 4096, "five pieces per lane");
+  const u32x4 z = {0, 0, 0, 0};
+  const uint32_t c0 = lane, c1 = kWave + lane, c2 = 2 * kWave + lane, c3 = 3 * kWave + lane, c4 = 4 * kWave + lane;
+  const uint8_t *g = out - sn;
+  const u32x4 v0 = c0 <= last && c0 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c0) : z;
+  const u32x4 v1 = c1 <= last && c1 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c1) : z;
+  const u32x4 v2 = c2 <= last && c2 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c2) : z;
+  const u32x4 v3 = c3 <= last && c3 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c3) : z;
+  const u32x4 v4 = c4 <= last && c4 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c4) : z;
+  if (c0 <= last) *(lds_u128 *)(stg + 16u * c0) = v0;
+  if (c1 <= last) *(lds_u128 *)(stg + 16u * c1) = v1;
+  if (c2 <= last) *(lds_u128 *)(stg + 16u * c2) = v2;
+  if (c3 <= last) *(lds_u128 *)(stg + 16u * c3) = v3;
+  if (c4 <= last) *(lds_u128 *)(stg + 16u * c4) = v4;
+  vm_quiesce();
+  return (int32_t)(16u * cmin) - sn;
+}
+
+// Longest remaining work first: the wavefronts of a SIMD compete for its issue slots, and a launch
+// ends with its slowest block.  What is left of the compressed block stands for the work left.
+__device__ __forceinline__ void prio_by_left(uint32_t left) {
+#ifndef LZ4MI_NO_PRIO
+  if (left >= kPrio3) __builtin_amdgcn_s_setprio(3);
+  else if (left >= kPrio2) __builtin_amdgcn_s_setprio(2);
+  else if (left >= kPrio1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
+// One wavefront per block, batch after batch: the form for launches that fill the chip (sixteen blocks per CU).
 template <bool STRICT, bool HAS_PREFIX>
 __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                 const uint64_t op_start, uint32_t cap, uint32_t back_limit,
@@ -516,334 +947,36 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   uint32_t fl = 0;          // output in front of this position is in memory; [fl, op) is in the buffer only
   int32_t vlo = 0;          // the buffer holds output positions [max(vlo, sbase), op)
   uint32_t sneg = kH + goff;  // buffer offset of position p is p + sneg (sneg = -sbase)
-  int32_t wb = 0;
-  uint32_t wlim = 0;
-  bool have_win = false;
-  bool dense = false;     // token chain: tokens are close together (chunk steps) or far apart (scalar steps)
-  uint32_t shortrun = 0;  // scalar steps in a row that were short
+  ParseCtx pc = {0, 0, false, false, 0};
   int32_t st = LZ4MI_OK;
-  PH_DECL
 
   for (;;) {
     bool general = true;
-    PH(7);
     if (in_end - ip >= 8u) {
-#ifndef LZ4MI_NO_PRIO
-      // Longest remaining work first: the wavefronts of a SIMD compete for its issue slots, and a launch
-      // ends with its slowest block.  What is left of the compressed block stands for the work left.
-      {
-        const uint32_t left = in_end - ip;
-        if (left >= kPrio3) __builtin_amdgcn_s_setprio(3);
-        else if (left >= kPrio2) __builtin_amdgcn_s_setprio(2);
-        else if (left >= kPrio1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
-#endif
-      // ---- window: keep it while a typical sequence still fits behind ip, or it holds the block's end
-      if (!have_win || !((ip - (uint32_t)wb) + kSeqTyp <= kCw || (uint32_t)(wb + (int32_t)kCw) >= in_end)) {
-        cw_load(cw, src, in_end, ip, lane, wb, wlim);
-        have_win = true;
-        PH_CNT(13);
-      }
-      PH(12);
+      prio_by_left(in_end - ip);
       // ---- slide the buffer so that the batch starts right behind kH bytes of history
-      {
-        const uint32_t shift = (op + sneg - kH) & ~15u;  // op + sneg >= kH always
-        if (shift) {
-          u32x4 v[kH / 1024 + 1];
-#pragma unroll
-          for (uint32_t u = 0; u <= kH / 1024; u++) {
-            const uint32_t c = u * kWave + (u < kH / 1024 ? lane : 0u);
-            v[u] = *(const lds_u128 *)(stg + shift + 16u * c);
-          }
-#pragma unroll
-          for (uint32_t u = 0; u <= kH / 1024; u++) {
-            const uint32_t c = u * kWave + (u < kH / 1024 ? lane : 0u);
-            *(lds_u128 *)(stg + 16u * c) = v[u];
-          }
-          sneg -= shift;
-        }
+      const uint32_t shift = (op + sneg - kH) & ~15u;  // op + sneg >= kH always
+      if (shift) {
+        stg_slide(stg, shift, kH + 16u, lane);
+        sneg -= shift;
       }
-      PH(14);
-      // ---- chain of token starts.  Only where the tokens are is found here, under the assumption that no
-      // match length has a second extension byte; the positions go into a list, lane j then reads sequence j
-      // in full, and a sequence whose real successor is not the next position of the list ends the batch.
-      // Two ways to step: where tokens are dense, lane p of a 64-byte chunk parses byte a + p as a token
-      // and the real starts are followed with one cross-lane read each; where literal runs are long (one
-      // token per chunk), the token is read into scalar registers and parsed there.
-      uint32_t a = ip - (uint32_t)wb, count = 0, tot = 0;
-      bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
-      while (count < kWave && tot <= kBatchOut - 512u) {
-        if (dense && count <= kWave - 22u) {
-          const uint32_t t4 = cw32(cw, a + lane);
-          const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
-          const bool isl = ll0 == 15u;
-          const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
-          // where the token behind this one starts; a token that is not for the chain (or not inside the window)
-          // points past every lane and carries its own lane, so the walk is one cross-lane read and one test per token
-          const uint32_t link = (a + nx <= wlim && !(isl && e1 == 255u)) ? nx : 0x8000u | lane;
-          uint64_t starts = 0;
-          uint32_t r = 0;
-          do {
-            starts |= 1ull << r;
-            r = rdlane(link, r);
-          } while (r < kWave);
-          const bool notok = (r & 0x8000u) != 0u;
-          if (notok) {  // the chain ends in front of that token
-            r &= 0x7fffu;
-            starts &= ~(1ull << r);
-          }
-          tl[(starts >> lane) & 1ull ? count + mbcnt64(starts) : 2u * kWave] = (uint16_t)(a + lane);
-          const uint32_t n = (uint32_t)__builtin_popcountll(starts);
-          count += n;
-          tot += r + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
-          a += r;
-          dense = n >= 2u && !notok;
-          continue;
-        }
-        // one token, in scalar registers
-        if (a + 4u > wlim) { stopped = true; break; }
-        const uint64_t t8v = cw64(cw, a);
-        const uint32_t lo = uni((uint32_t)t8v), hi = uni((uint32_t)(t8v >> 32));
-        const uint32_t ll0 = (lo >> 4) & 15u;
-        uint32_t ll = ll0, xl = 0;
-        if (ll0 == 15u) {
-          const uint32_t e1 = (lo >> 8) & 255u;
-          ll = 15u + e1;
-          xl = 1;
-          if (e1 == 255u) {  // up to seven extension bytes
-            const uint64_t ext = (((uint64_t)hi << 32) | lo) >> 8;
-            const uint32_t nff = ff_bytes(ext);
-            if (nff == 7u) { stopped = true; break; }
-            ll = 15u + 255u * nff + ((uint32_t)(ext >> (8u * nff)) & 255u);
-            xl = nff + 1u;
-          }
-        }
-        const uint32_t nx = a + 1u + xl + ll + 2u + ((lo & 15u) == 15u ? 1u : 0u);
-        if (nx > wlim) { stopped = true; break; }
-        tl[count] = (uint16_t)a;
-        count++;
-        tot += ll + 64u;
-        shortrun = nx - a < 24u ? shortrun + 1u : 0u;
-        dense = shortrun >= 2u;
-        a = nx;
+      SeqLane q;
+      const int32_t lo = vlo > -(int32_t)sneg ? vlo : -(int32_t)sneg;  // lowest position the buffer holds
+      const BatchPlan bp = parse_batch(src, in_end, ip, op, cap, back_limit, lo, fl, cw, tl, lane, pc, q);
+      general = bp.general;
+      if (bp.nb) {
+        copy_far<HAS_PREFIX, kStgBytes>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
+        copy_literals<kStgBytes>(cw, stg, sneg, q, lane);
+        copy_matches<kStgBytes>(stg, sneg, bp.nb, q, lane);
+        // ---- the batch goes to memory in aligned 16-byte pieces
+        fl = stg_flush(stg, out, sneg, fl, bp.b1, false, lane);
+        op = bp.b1;
       }
-      uint32_t ip_stop = (uint32_t)wb + a;
-      // A token that ends the chain: too many extension bytes, the end of the block, or the end of the window.
-      // A window that was loaded at this token holds any sequence the batch takes, so there it is not the window.
-      general = stopped && ((uint32_t)(wb + (int32_t)kCw) >= in_end || a < 16u);
-      if (stopped && !general) have_win = false;
-      PH(0);
-
-      if (count) {
-        // ---- lane j owns sequence j
-        const bool mine = lane < count;
-        const uint32_t ta = tl[lane], tn = tl[lane + 1u];
-        const SeqFields g = seq_long(cw, ta, wlim);
-        const uint32_t ls = g.ls, ll = mine ? g.ll : 0u, ml = mine ? g.ml : 0u, dist = g.dist;
-        // the sequences in front of the first one that is not for the batch, or whose successor is not the
-        // next token of the list, are real
-        const uint64_t nokm = ballot(mine && !g.ok), brkm = ballot(mine && lane + 1u < count && g.nx != tn);
-        const uint32_t nnok = nokm ? (uint32_t)__builtin_ctzll(nokm) : kWave;
-        const uint32_t nbrk = brkm ? (uint32_t)__builtin_ctzll(brkm) + 1u : kWave;
-        const uint32_t nreal = nnok < nbrk ? (nnok < count ? nnok : count) : (nbrk < count ? nbrk : count);
-        const uint32_t incl = wave_incl_scan(ll + ml);
-        const uint32_t o_lit = op + incl - (ll + ml);  // where the literals go
-        const uint32_t o_mat = o_lit + ll;             // where the match goes
-        // lz4_block_decoder.dart:33-35,61-63 and byte_writer.dart:97-104: a sequence that would fail
-        // any of them is left to the general loop, which names the failure
-        const bool good = incl <= cap - op && dist != 0u && (uint64_t)dist <= (uint64_t)o_mat + back_limit;
-        const int32_t sp = (int32_t)o_mat - (int32_t)dist;  // match source (may lie in front of the block)
-        const int32_t lo = vlo > -(int32_t)sneg ? vlo : -(int32_t)sneg;  // lowest position the buffer holds
-        bool far = mine && sp < lo;
-        // an out-of-buffer source that is longer than the fetch below takes, or that reaches into output
-        // not yet in memory (possible right after the general loop): general loop
-        const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
-        const uint64_t realm = nreal < kWave ? (1ull << nreal) - 1ull : ~0ull;
-        const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > kBatchOut) & realm;
-        const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
-        const uint32_t nover = overm ? (uint32_t)__builtin_ctzll(overm) : kWave;
-        uint32_t nb = nreal;
-        if (nbad < nb || nover < nb) {  // a sequence that fails a check, or the batch is full
-          nb = nbad < nover ? nbad : nover;
-          general = nbad <= nover;
-          have_win = true;
-          ip_stop = (uint32_t)wb + rdlane(ta, nb);
-        } else if (nreal < count && nnok <= nbrk) {  // a token that is not for the batch
-          const uint32_t at = rdlane(ta, nreal);
-          ip_stop = (uint32_t)wb + at;
-          general = (uint32_t)(wb + (int32_t)kCw) >= in_end || at < 16u;
-          have_win = general;
-        } else {
-          // the chain went on behind a match with more extension bytes than it assumed (then the rest of the list
-          // is void), or the list is used up: go on at the real successor of the last sequence taken
-          const uint32_t nxl = rdlane(g.nx, nb - 1u);
-          if (nreal < count || nxl != a) {
-            general = false;
-            have_win = true;
-          }
-          ip_stop = (uint32_t)wb + nxl;
-        }
-        const uint32_t b1 = op + (nb ? rdlane(incl, nb - 1u) : 0u);
-        far = far && lane < nb;
-        const bool near = lane < nb && !far;
-        // match descriptors: source and destination as buffer offsets; length (0: nothing to do here) and distance
-        // Every value the copy loop needs sits in a register of its own, ready for one cross-lane read: the loop
-        // runs once per match on the scalar unit, which the wavefronts of a CU share, and unpacking there costs
-        // more than the extra reads.  An overlapping match (byte_writer.dart:116-118) repeats its period:
-        // lane mod dist without a division is lane - ((lane * mg) >> 16) * dist with mg = 65536 / dist + 1
-        // (off by less than 1 / dist for lane < 64), and a piece of 64 bytes moves on by 64 mod dist.  A plain
-        // copy has mg = 0 (lane mod dist = lane where it matters), step 64 and a period it never reaches.
-        const bool ovl = dist < ml;
-        const uint32_t dsafe = dist ? dist : 1u;
-        const uint32_t m_src = ((uint32_t)sp + sneg) & 0xffffu, m_dst = o_mat + sneg;
-        const uint32_t m_len = near ? ml : 0u, m_per = ovl ? dist : 0xffffu;
-        const uint32_t m_mg = ovl ? 65536u / dsafe + 1u : 0u, m_step = ovl ? 64u % dsafe : kWave;
-        PH(1);
-        if (nb) {
-#ifdef LZ4MI_PROFILE
-          ph_c_[8 * 64] += 1; ph_c_[9 * 64] += nb; ph_c_[10 * 64] += (uint32_t)__builtin_popcountll(ballot(far));
-#endif
-          // ---- matches whose source is older than the buffer: fetched from memory, four per round trip
-          for (uint64_t fm = ballot(far); fm;) {
-            int32_t fs[4];
-            uint32_t fd[4], fn[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-              fs[u] = 0; fd[u] = 0; fn[u] = 0;
-              if (fm) {
-                const uint32_t j = (uint32_t)__builtin_ctzll(fm);
-                fm &= fm - 1ull;
-                fs[u] = (int32_t)rdlane((uint32_t)sp, j);
-                fd[u] = rdlane(o_mat, j) + sneg;
-                fn[u] = rdlane(ml, j);
-              }
-            }
-            uint32_t v[4][kFarMax / kWave];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-#pragma unroll
-              for (uint32_t t = 0; t < kFarMax / kWave; t++) {
-                v[u][t] = 0;
-                if (t * kWave < fn[u]) {  // lanes past the end read the last byte again
-                  const uint32_t idx = t * kWave + lane < fn[u] ? t * kWave + lane : fn[u] - 1u;
-                  const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
-                  v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
-                }
-              }
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-#pragma unroll
-              for (uint32_t t = 0; t < kFarMax / kWave; t++) {
-                if (t * kWave < fn[u]) {
-                  const uint32_t idx = t * kWave + lane;
-                  stg[idx < fn[u] ? fd[u] + idx : kDummy + lane] = (uint8_t)v[u][t];
-                }
-              }
-            }
-            vm_quiesce();
-          }
-          PH(2);
-
-          // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
-          // off (that costs more than the copies) and every LDS access is aligned (an unaligned one stalls the
-          // LDS pipe of the CU): the up to three bytes in front of the first aligned dword of the destination
-          // and the up to three behind the last go byte by byte, as does a run too short to hold an aligned
-          // dword; the dwords in between are put together from the aligned dwords of the window they straddle.
-          // What does not apply writes to a dummy slot.
-          {
-            const uint32_t n = lane < nb ? ll : 0u;
-            const uint32_t lsx = lane < nb ? ls : 0u;
-            const uint32_t d0 = o_lit + sneg;
-            const uint32_t n1 = n < 64u ? n : 64u;
-            const uint32_t head = (0u - d0) & 3u;
-            const bool mid = n1 >= head + 4u;
-            const uint32_t body = mid ? (n1 - head) >> 2 : 0u;  // aligned dwords, at most 16
-            const uint32_t tail = mid ? (n1 - head) & 3u : 0u;
-            {
-              const uint32_t sb = lsx + head, sh = sb & 3u;
-              const lds_u32 *q = (const lds_u32 *)(cw + ((sb < kCwTop ? sb : kCwTop) & ~3u));
-              uint32_t wd[17];
-#pragma unroll
-              for (uint32_t k = 0; k < 17; k++) wd[k] = q[k];
-              lds_u32 *d = (lds_u32 *)(stg + d0 + head);
-              lds_u32 *dummy = (lds_u32 *)(stg + kDummy + 64u);
-#pragma unroll
-              for (uint32_t k = 0; k < 16; k++) *(k < body ? d + k : dummy) = __builtin_amdgcn_alignbyte(wd[k + 1], wd[k], sh);
-            }
-            {
-              // six single bytes: head (or the whole of a short run) from the run's first bytes, tail from its last
-              const uint64_t f8 = cw64(cw, lsx);
-              const uint32_t toff = head + 4u * body;
-              const uint32_t t4 = cw32(cw, lsx + toff);
-              const uint32_t nfirst = mid ? head : n1;  // bytes taken from the front (at most six)
-#pragma unroll
-              for (uint32_t i = 0; i < 6; i++) {
-                const bool front = i < nfirst;
-                const bool back = mid && i >= 3u && i - 3u < tail;
-                const uint32_t v = front ? (uint32_t)(f8 >> (8u * i)) : t4 >> (8u * (i - 3u < 3u ? i - 3u : 0u));
-                stg[front ? d0 + i : back ? d0 + toff + (i - 3u) : kDummy + lane] = (uint8_t)v;
-              }
-            }
-            // runs longer than 64 bytes, one after the other: bytes 56.. of the run, 256 bytes per step, the same way
-            // with the whole wavefront on one run (at least 9 bytes are left)
-            for (uint64_t lm = ballot(n > 64u); lm; lm &= lm - 1ull) {
-              const uint32_t j = (uint32_t)__builtin_ctzll(lm);
-              const uint32_t s0 = rdlane(lsx, j) + 56u, e0 = rdlane(d0, j) + 56u, rem = rdlane(n, j) - 56u;
-              const uint32_t hb = (0u - e0) & 3u;
-              const uint32_t bd = (rem - hb) >> 2, tl3 = (rem - hb) & 3u;
-              {
-                const bool edge = lane < hb || (lane >= 4u && lane - 4u < tl3);
-                const uint32_t eo = lane < hb ? lane : hb + 4u * bd + (lane - 4u);
-                const uint32_t v = cw[s0 + (edge ? eo : 0u)];
-                stg[edge ? e0 + eo : kDummy + lane] = (uint8_t)v;
-              }
-              const uint32_t sb = s0 + hb, sh = sb & 3u;
-              const lds_u32 *q = (const lds_u32 *)(cw + (sb & ~3u));
-              lds_u32 *d = (lds_u32 *)(stg + e0 + hb);
-              for (uint32_t k0 = 0; k0 < bd; k0 += kWave) {
-                const uint32_t k = k0 + lane;
-                const uint32_t kk = k < bd ? k : 0u;
-                const uint32_t v = __builtin_amdgcn_alignbyte(q[kk + 1u], q[kk], sh);
-                *(k < bd ? d + k : (lds_u32 *)(stg + kDummy + 64u)) = v;
-              }
-            }
-          }
-          PH(3);
-
-          // ---- matches in order, buffer -> buffer.  LDS operations of a wavefront execute in issue order, so a
-          // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
-          // byte by byte: output byte k is byte k mod dist of the period in front of the match.
-          // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
-          for (uint32_t j = 0; j < nb; j++) {
-            const uint32_t m = rdlane(m_len, j);
-            if (!m) continue;
-            const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
-            const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
-            uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
-            for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
-              const uint32_t v = stg[ms + r];
-              stg[k0 + lane < m ? md + k0 : kDummy + lane] = (uint8_t)v;
-              r += step;
-              r = r >= per ? r - per : r;
-            }
-          }
-          PH(4);
-
-          // ---- the batch goes to memory in aligned 16-byte pieces
-          fl = stg_flush(stg, out, sneg, fl, b1, false, lane);
-          op = b1;
-          PH(5);
-        }
-      }
-      ip = ip_stop;
+      ip = bp.ip_stop;
     }
     if (!general) continue;
 
     // ---- one sequence through the general loop (and every end of a block)
-    PH(7);
-    PH_CNT(11);
     fl = stg_flush(stg, out, sneg, fl, op, true, lane);
     uint32_t di = 0, dn = 0;
     st = decode_run<STRICT, HAS_PREFIX, true>(src + ip, in_end - ip, dst, op_start + op, cap - op, back_limit + op,
@@ -851,37 +984,156 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     ip += di;
     op += dn;
     fl = op;
-    PH(6);
     if (st != kSwitchRun) break;
-    // The general loop used the buffer for itself: bring back the history, kH bytes of this block's
-    // output in whole aligned 16-byte pieces, if more sequences follow.
     sneg = kH + ((op + goff) & 15u) - op;
     vlo = (int32_t)op;
-    if (in_end - ip >= 8u && op > 0) {
-      // piece c holds positions [16c - sneg, 16c - sneg + 16); the last piece that holds a byte of output is
-      // the one of position op - 1
-      const uint32_t last = (op - 1u + sneg) >> 4;  // <= kH / 16
-      // lowest piece that lies inside the block's output
-      const int32_t sn = (int32_t)sneg;
-      const uint32_t cmin = sn > 0 ? (uint32_t)(sn + 15) >> 4 : 0u;
-      u32x4 v[kH / 1024 + 1];
-#pragma unroll
-      for (uint32_t u = 0; u <= kH / 1024; u++) {
-        const uint32_t c = u * kWave + lane;
-        v[u] = u32x4{0, 0, 0, 0};
-        if (c <= last && c >= cmin) v[u] = *(const u32x4 *)(out + ((int32_t)(16u * c) - sn));
-      }
-#pragma unroll
-      for (uint32_t u = 0; u <= kH / 1024; u++) {
-        const uint32_t c = u * kWave + lane;
-        if (c <= last) *(lds_u128 *)(stg + 16u * c) = v[u];
-      }
-      vm_quiesce();
-      vlo = (int32_t)(16u * cmin) - sn;
-    }
-    PH(6);
+    if (in_end - ip >= 8u && op > 0) vlo = stg_restore(stg, out, op, sneg, lane);
   }
-  PH_FLUSH(g_dec_phase, lane);
+#ifndef LZ4MI_NO_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  out_len = op;
+  return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two wavefronts per block.  A block on one wavefront is one chain of dependent steps (find the tokens, read the
+// sequences, place the literals, copy match after match), each waiting on the LDS round trip of the one before, and a
+// launch of few blocks per wavefront ends with its slowest block.  Here the parsing wavefront (0) finds batch k + 1
+// and places its literals while the copying wavefront (1) fetches and copies the matches of batch k and writes it to
+// memory; they meet at a barrier twice per batch.  Everything the parser needs from the copier's side it can work out
+// itself: where the buffer will stand (the slide is a function of the batch ends) and how far the output will have
+// been written to memory.  The general loop runs on the copier with the parser waiting, and hands the state back
+// through `ctl`.
+
+template <bool STRICT, bool HAS_PREFIX>
+__device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
+                                                     const uint64_t op_start, uint32_t cap, uint32_t back_limit,
+                                                     const uint8_t *__restrict__ prefix, uint32_t prefix_len,
+                                                     lds_u8 *stg, lds_u8 *cw, lds_u16 *tl,
+                                                     __attribute__((address_space(3))) PairShared *sh, uint32_t role,
+                                                     uint32_t lane, uint32_t &out_len) {
+  const uint32_t in_end = src_len;
+  uint8_t *const out = dst + op_start;
+  const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
+  // both wavefronts keep the same picture: the batch that is being copied starts at (ip, op), fl and the layout
+  // (sneg, vlo) are the copier's
+  uint32_t ip = 0, op = 0, fl = 0;
+  int32_t vlo = 0;
+  uint32_t sneg = kH + goff;
+  ParseCtx pc = {0, 0, false, false, 0};
+  int32_t st = LZ4MI_OK;
+  PH_DECL
+
+  for (;;) {
+    // ---- fill: behind the block's start or the general loop the pipeline starts with a batch of nothing, so the
+    // parser makes the first real one with nobody copying yet.  The layout stands as that batch needs it (no slide).
+    if (role == 0 && lane < 4) sh->hdr[0][lane] = lane == 1 ? op : lane == 2 ? ip : 0u;
+    PH(0);
+    __syncthreads();
+    PH(1);
+    uint32_t cur = 0;
+    for (;;) {
+      const uint32_t nb = uni(sh->hdr[cur][0]), b1 = uni(sh->hdr[cur][1]), ip_stop = uni(sh->hdr[cur][2]);
+      const bool stop = uni(sh->hdr[cur][3]) != 0u;
+      // where the buffer stands for the batch after this one, and how far memory is written by then
+      const uint32_t shift = stop ? 0u : (b1 + sneg - kH) & ~15u;
+      const uint32_t fl_next = flush_end(sneg, fl, b1);
+      if (role == 1) {
+        if (nb) {
+          SeqLane q;
+          q.ls = 0; q.ll = 0; q.o_lit = 0;
+          q.sp = (int32_t)sh->desc[cur][0][lane];
+          q.o_mat = sh->desc[cur][1][lane];
+          const uint32_t mf = sh->desc[cur][2][lane];
+          q.ml = mf & 0x7fffffffu;
+          q.far = (mf >> 31) != 0u;
+          q.dist = sh->desc[cur][3][lane];
+          if (lane >= nb) { q.ml = 0; q.far = false; q.dist = 1; }
+          prio_by_left(in_end - ip);
+          copy_far<HAS_PREFIX, kStgPair>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
+          PH(2);
+          copy_matches<kStgPair>(stg, sneg, nb, q, lane);
+          PH(3);
+        }
+        (void)stg_flush(stg, out, sneg, fl, b1, false, lane);  // ends at fl_next
+        PH(4);
+      } else if (!stop) {
+        BatchPlan bp = {0, b1, ip_stop, true};
+        SeqLane q;
+        if (in_end - ip_stop >= 8u) {
+          prio_by_left(in_end - ip_stop);
+          const uint32_t sneg_next = sneg - shift;
+          const int32_t lo = vlo > -(int32_t)sneg_next ? vlo : -(int32_t)sneg_next;
+          uint32_t at = ip_stop;
+          do {
+            bp = parse_batch(src, in_end, at, b1, cap, back_limit, lo, fl_next, cw, tl, lane, pc, q);
+            at = bp.ip_stop;
+          } while (!bp.nb && !bp.general);
+          PH(5);
+          if (bp.nb) copy_literals<kStgPair>(cw, stg, sneg, q, lane);  // the buffer stands as the batch being copied needs it
+          PH(6);
+        }
+        if (bp.nb) {
+          sh->desc[cur ^ 1u][0][lane] = (uint32_t)q.sp;
+          sh->desc[cur ^ 1u][1][lane] = q.o_mat;
+          sh->desc[cur ^ 1u][2][lane] = q.ml | (q.far ? 0x80000000u : 0u);
+          sh->desc[cur ^ 1u][3][lane] = q.dist;
+        }
+        if (lane < 4)
+          sh->hdr[cur ^ 1u][lane] = lane == 0 ? bp.nb : lane == 1 ? bp.b1 : lane == 2 ? bp.ip_stop : (bp.general ? 1u : 0u);
+      }
+      __syncthreads();
+      PH(7);
+      op = b1;
+      ip = ip_stop;
+      fl = fl_next;
+      if (stop) break;
+      // ---- slide: the next batch starts right behind kH bytes of history; its literals are already in the buffer
+      if (shift) {
+        if (role == 1) stg_slide(stg, shift, kH + 16u + (uni(sh->hdr[cur ^ 1u][1]) - b1) + 16u, lane);
+        sneg -= shift;
+      }
+      PH(8);
+      __syncthreads();
+      PH(9);
+      cur ^= 1u;
+    }
+    // ---- one sequence through the general loop (and every end of a block), on the copying wavefront
+    if (role == 0) {
+      pair_serve(sh, lane);
+    } else {
+      fl = stg_flush(stg, out, sneg, fl, op, true, lane);
+      uint32_t di = 0, dn = 0;
+      st = decode_run<STRICT, HAS_PREFIX, true, true>(src + ip, in_end - ip, dst, op_start + op, cap - op, back_limit + op,
+                                                      prefix, prefix_len, stg, lane, di, dn, sh);
+      ip += di;
+      op += dn;
+      fl = op;
+      if (st == kSwitchRun) {
+        sneg = kH + ((op + goff) & 15u) - op;
+        vlo = (int32_t)op;
+        if (in_end - ip >= 8u && op > 0) vlo = stg_restore(stg, out, op, sneg, lane);
+      }
+      if (lane < 7)
+        sh->ctl[lane] = lane == 0 ? ip : lane == 1 ? op : lane == 2 ? fl : lane == 3 ? sneg : lane == 4 ? (uint32_t)vlo
+                        : lane == 5 ? (uint32_t)st : (st != kSwitchRun ? 1u : 0u);
+      if (lane == 0) sh->req[0] = kReqEnd;
+      PH(10);
+      __syncthreads();
+    }
+    PH(11);
+    ip = uni(sh->ctl[0]);
+    op = uni(sh->ctl[1]);
+    fl = uni(sh->ctl[2]);
+    sneg = uni(sh->ctl[3]);
+    vlo = (int32_t)uni(sh->ctl[4]);
+    st = (int32_t)uni(sh->ctl[5]);
+    const bool done = uni(sh->ctl[6]) != 0u;
+    __syncthreads();  // ctl is read before the next general loop writes it
+    if (done) break;
+  }
+  PH_FLUSH(g_dec_phase + role * PH_SLOTS, lane);
 #ifndef LZ4MI_NO_PRIO
   __builtin_amdgcn_s_setprio(0);
 #endif
@@ -940,18 +1192,85 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
-// Linked ("dependent") blocks: block b may reference the 64 KiB that precede it in the
-// frame output, topped up from the dictionary while the output is shorter than that
-// (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
-// serial, so one wavefront walks the blocks in order over one contiguous output.
-__global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
+// One workgroup of two wavefronts per block: the form for launches that leave wavefront slots empty (a block is
+// done in 0.6 of the time a wavefront on its own takes, but a CU holds eight such blocks instead of sixteen).
+template <bool STRICT, bool HAS_PREFIX>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_pair_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgPairAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
+  __shared__ __attribute__((aligned(16))) PairShared s_sh;
+  const uint32_t lane = lane_id();
+  const uint32_t role = uni(threadIdx.x / kWave);
   lds_u8 *stg = (lds_u8 *)s_stg;
   lds_u8 *cw = (lds_u8 *)s_cw;
   lds_u16 *tl = (lds_u16 *)s_tl;
+  __attribute__((address_space(3))) PairShared *sh = (__attribute__((address_space(3))) PairShared *)&s_sh;
+  // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
+  const uint8_t *prefix = a.dict;
+  const uint32_t prefix_len = a.dict_len;
+  // When the launch has a workgroup for every block, a workgroup's block is its own index; larger
+  // batches are handed out through the queue, where a workgroup's first block is still its own
+  // index (thousands of workgroups popping one queue head at launch serialise on it).
+  const uint32_t ngroups = gridDim.x;
+  const bool direct = a.nblocks <= ngroups;
+  uint32_t b = uni(blockIdx.x);
+  for (;;) {
+    if (b >= a.nblocks) break;
+    if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
+    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    const uint32_t src_len = uni(block_src_len(a, b));
+    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
+    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    uint32_t out_len = 0;
+#ifdef LZ4MI_DEC_SPANS
+    if (role == 1 && lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
+#endif
+    int32_t st = LZ4MI_OK;
+    const uint32_t stored = a.stored_len ? uni(a.stored_len[b]) : 0u;
+    if (stored) {  // a stored block rides in the same queue: its copy overlaps the issue-bound blocks
+      const uint32_t half = (stored / 2u) & ~15u;
+      if (role == 0) wave_copy(dst, src, half, lane);
+      else wave_copy(dst + half, src + half, stored - half, lane);
+      vm_quiesce();
+      out_len = stored;
+    } else {
+      st = decode_block_pair<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg, cw, tl, sh,
+                                                 role, lane, out_len);
+    }
+#ifdef LZ4MI_DEC_SPANS
+    if (role == 1 && lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (role == 1 && lane == 0) {
+      a.out_len[b] = out_len;
+      a.status[b] = st;
+    }
+    if (direct) break;
+    if (role == 0) {
+      const uint32_t nx = next_block(counter, lane);
+      if (lane == 0) sh->next = nx;
+    }
+    __syncthreads();
+    b = ngroups + uni(sh->next);
+    __syncthreads();  // next is read before the parsing wavefront writes it again
+  }
+}
+
+// Linked ("dependent") blocks: block b may reference the 64 KiB that precede it in the
+// frame output, topped up from the dictionary while the output is shorter than that
+// (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
+// serial, so one workgroup walks the blocks in order over one contiguous output.
+__global__ __launch_bounds__(128) void decode_chain_kernel(ChainArgs c) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgPairAlloc];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
+  __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
+  __shared__ __attribute__((aligned(16))) PairShared s_sh;
+  lds_u8 *stg = (lds_u8 *)s_stg;
+  lds_u8 *cw = (lds_u8 *)s_cw;
+  lds_u16 *tl = (lds_u16 *)s_tl;
+  __attribute__((address_space(3))) PairShared *sh = (__attribute__((address_space(3))) PairShared *)&s_sh;
   const uint32_t lane = lane_id();
+  const uint32_t role = uni(threadIdx.x / kWave);
   uint64_t start = 0;
   uint32_t b = 0;
   for (; b < c.nblocks; b++) {
@@ -961,25 +1280,29 @@ __global__ __launch_bounds__(64) void decode_chain_kernel(ChainArgs c) {
     uint32_t produced = 0;
     int32_t st = LZ4MI_OK;
     if (c.raw[b]) {
-      wave_copy(c.dst + start, payload, len, lane);
+      if (role == 1) {
+        wave_copy(c.dst + start, payload, len, lane);
+        vm_quiesce();
+      }
       produced = len;
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, tl, lane,
-                                     produced);
+      st = decode_block_pair<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, tl, sh,
+                                          role, lane, produced);
     }
-    if (lane == 0) {
+    if (role == 1 && lane == 0) {
       c.out_len[b] = produced;
       c.status[b] = st;
     }
     if (st != LZ4MI_OK) { b++; break; }
     start += produced;
   }
-  for (uint32_t k = b + lane; k < c.nblocks; k += kWave) {  // blocks after an error never ran
-    c.out_len[k] = 0;
-    c.status[k] = LZ4MI_OK;
-  }
+  if (role == 1)
+    for (uint32_t k = b + lane; k < c.nblocks; k += kWave) {  // blocks after an error never ran
+      c.out_len[k] = 0;
+      c.status[k] = LZ4MI_OK;
+    }
 }
 
 #ifdef LZ4MI_DEC_SPANS
@@ -989,9 +1312,9 @@ extern "C" void lz4mi_debug_dec_spans(unsigned long long *out, int n) {
 #endif
 #ifdef LZ4MI_PROFILE
 extern "C" void lz4mi_debug_dec_phases(unsigned long long *out, int reset) {
-  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_phase), sizeof(unsigned long long) * PH_SLOTS);
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dec_phase), sizeof(unsigned long long) * 2 * PH_SLOTS);
   if (reset) {
-    unsigned long long z[PH_SLOTS] = {0};
+    unsigned long long z[2 * PH_SLOTS] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_phase), z, sizeof z);
   }
 }
@@ -999,7 +1322,7 @@ extern "C" void lz4mi_debug_dec_phases(unsigned long long *out, int reset) {
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s) {
   if (!c.nblocks) return;
-  hipLaunchKernelGGL(decode_chain_kernel, dim3(1), dim3(64), 0, s, c);
+  hipLaunchKernelGGL(decode_chain_kernel, dim3(1), dim3(128), 0, s, c);
 }
 
 // A launch ends when its longest block does, and the queue hands blocks out in order: a long block
@@ -1055,26 +1378,42 @@ __global__ __launch_bounds__(256) void decode_order_place_kernel(uint32_t nblock
 constexpr uint32_t kMix = 3;            // streamed blocks per heavy block in the queue of a long launch
 constexpr uint32_t kMixFromRounds = 8;  // a launch is long from this many blocks per resident wavefront
 
-// Resident wavefronts (= workgroups) per CU of a decode kernel: bounded by its LDS and registers.
+// 0: the form follows the launch size; 1: one wavefront per block; 2: two wavefronts per block.
+// LZ4MI_DEC_FORM=single|pair sets the initial value, lz4mi_set_decode_form changes it.
+static std::atomic<int> g_decode_form{[] {
+  const char *e = getenv("LZ4MI_DEC_FORM");
+  return !e ? 0 : e[0] == 'p' ? 2 : e[0] == 's' ? 1 : 0;
+}()};
+int set_decode_form(int form) { return g_decode_form.exchange(form, std::memory_order_relaxed); }
+
+// Resident workgroups per CU of a decode kernel: bounded by its LDS and registers.
 template <typename K>
-static uint32_t resident_per_cu(K kernel) {
+static uint32_t resident_per_cu(K kernel, int threads) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 64, 0) != hipSuccess || n < 1) n = 8;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, 0) != hipSuccess || n < 1) n = 8;
   return (uint32_t)n;
 }
 
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
                    uint32_t cu_count, hipStream_t s) {
-  // one wavefront per workgroup; as many as stay resident (one that is not would hold its first block back)
-  static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>), resident_per_cu(decode_kernel<false, true>),
-                                     resident_per_cu(decode_kernel<true, false>), resident_per_cu(decode_kernel<true, true>)};
+  // as many workgroups as stay resident (one that is not would hold its first block back)
+  static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>, 64), resident_per_cu(decode_kernel<false, true>, 64),
+                                     resident_per_cu(decode_kernel<true, false>, 64), resident_per_cu(decode_kernel<true, true>, 64)};
+  static const uint32_t pair_per_cu[4] = {
+      resident_per_cu(decode_pair_kernel<false, false>, 128), resident_per_cu(decode_pair_kernel<false, true>, 128),
+      resident_per_cu(decode_pair_kernel<true, false>, 128), resident_per_cu(decode_pair_kernel<true, true>, 128)};
   // streamed blocks behind every heavy one in the queue of a long launch (LZ4MI_DEC_MIX overrides; 0 = heavy first)
   static const int mix_env = [] {
     const char *e = getenv("LZ4MI_DEC_MIX");
     return e ? atoi(e) : -1;
   }();
+  const int form_env = g_decode_form.load(std::memory_order_relaxed);
   const bool pre = a.dict_len != 0;
-  const uint32_t slots = cu_count * per_cu[(strict ? 2 : 0) + (pre ? 1 : 0)];
+  const uint32_t v = (strict ? 2 : 0) + (pre ? 1 : 0);
+  // Few blocks (every one gets a resident pair of wavefronts): two wavefronts per block, each block done sooner.
+  // More blocks than that: one wavefront per block, twice as many blocks in flight.
+  const bool pair = form_env ? form_env == 2 : a.nblocks <= cu_count * pair_per_cu[v];
+  const uint32_t slots = cu_count * (pair ? pair_per_cu[v] : per_cu[v]);
   const uint32_t grid = a.nblocks < slots ? a.nblocks : slots;
   if (order && a.nblocks > grid) {  // only a queued launch has an order to choose
     // few blocks per wavefront: the launch ends with its slowest block, heavy blocks go first
@@ -1087,8 +1426,16 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
   } else {
     order = nullptr;
   }
-  dim3 g(grid), blk(64);
-  if (strict) {
+  dim3 g(grid), blk(pair ? 128 : 64);
+  if (pair) {
+    if (strict) {
+      if (pre) hipLaunchKernelGGL((decode_pair_kernel<true, true>), g, blk, 0, s, a, counter, order);
+      else hipLaunchKernelGGL((decode_pair_kernel<true, false>), g, blk, 0, s, a, counter, order);
+    } else {
+      if (pre) hipLaunchKernelGGL((decode_pair_kernel<false, true>), g, blk, 0, s, a, counter, order);
+      else hipLaunchKernelGGL((decode_pair_kernel<false, false>), g, blk, 0, s, a, counter, order);
+    }
+  } else if (strict) {
     if (pre) hipLaunchKernelGGL((decode_kernel<true, true>), g, blk, 0, s, a, counter, order);
     else hipLaunchKernelGGL((decode_kernel<true, false>), g, blk, 0, s, a, counter, order);
   } else {

@@ -75,6 +75,8 @@ void launch_decode_chain(const ChainArgs &c, hipStream_t s);
 // building it), or null: index order; order_cnt: two words, zero at launch.  The grid is sized to the wavefronts that stay resident.
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
                    uint32_t cu_count, hipStream_t s);
+// 0: by launch size, 1: one wavefront per block, 2: two wavefronts per block; returns the previous setting
+int set_decode_form(int form);
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
                         uint32_t grid, hipStream_t s);
 void launch_dict_prime(const uint8_t *dict, uint32_t dict_len, uint32_t *dict_table, hipStream_t s);

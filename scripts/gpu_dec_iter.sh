@@ -6,4 +6,4 @@ tail -2 gpurun_out/dec_tests.log
 timeout -k 10 200 python scripts/gpu_class_timing.py 2>&1 | grep class | tee gpurun_out/class_timing_iter.log || exit 1
 timeout -k 10 200 python bench.py > gpurun_out/bench_iter.json 2> gpurun_out/bench_iter.err || { tail gpurun_out/bench_iter.err; exit 1; }
 python -c "
-import json;d=json.load(open('gpurun_out/bench_iter.json'));print(d['value'],[(k['kernel'],round(k['ms'],3),round(k['frac'],3)) for k in d.get('roofline_all',[])] if 'roofline_all' in d else d['roofline'])"
+import json;d=json.load(open('gpurun_out/bench_iter.json'));print(d['value'], {k:(round(v['avg_launch_ms'],3),round(v['frac'],3)) for k,v in d['roofline_all'].items()})"

@@ -150,7 +150,19 @@ def _mutations(rng, blocks, per_block):
     return out
 
 
-def test_block_decoder_fuzz_status_parity(codec, oracle):
+@pytest.fixture(params=[0, 1, 2], ids=["form-by-size", "one-wavefront", "two-wavefronts"])
+def decode_form(request):
+    """The decoder's two launch forms (one or two wavefronts per block): results never depend on the form."""
+    from lz4_amd import _native as N
+    L = N.load()
+    prev = L.lz4mi_set_decode_form(request.param)
+    assert prev >= 0
+    yield request.param
+    L.lz4mi_set_decode_form(prev)
+
+
+
+def test_block_decoder_fuzz_status_parity(codec, oracle, decode_form):
     """Bit flips / truncations / garbage (the reference's fuzz idea,
     test/block/lz4_block_decoder_fuzz_test.dart:101-195): every block's status and,
     when it decodes, every byte equals the oracle's, strict and lenient."""
@@ -192,7 +204,7 @@ def test_block_decoder_fuzz_status_parity(codec, oracle):
     assert N.OK == 0
 
 
-def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle):
+def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle, decode_form):
     """Blocks made of thousands of short sequences (text through the HC encoder) take the
     decoder's second kernel, which decodes groups of sequences per step: status and bytes
     against the oracle for intact and damaged blocks, strict and lenient, with and without a
@@ -270,7 +282,7 @@ def _last_literals(lits):
     return bytes(out + lits)
 
 
-def test_block_decoder_long_overlapping_matches(codec, oracle):
+def test_block_decoder_long_overlapping_matches(codec, oracle, decode_form):
     """Matches longer than their distance (byte-serial copyMatch, lib/src/internal/byte_writer.dart:116-118)
     and longer than the decoder's short-copy path: every distance class (below / at / above a
     wavefront, around 16-byte alignment), lengths up to more than a block, sources that start inside
@@ -314,7 +326,7 @@ def test_block_decoder_long_overlapping_matches(codec, oracle):
                 assert out[k, :z].tobytes() == ref, (use_dict, strict, k)
 
 
-def test_block_decoder_queue_order_large_ragged_batch(codec, oracle):
+def test_block_decoder_queue_order_large_ragged_batch(codec, oracle, decode_form):
     """More blocks than resident wavefronts, so the launch goes through the work queue and its
     long-blocks-first order: blocks of very different sizes and kinds (literal-only, run-like, mixed,
     damaged) all come back with the oracle's bytes and status at their own index."""
@@ -674,7 +686,7 @@ def test_our_frames_through_lz4_cli(lz, tmp_path):
 
 # ------------------------------------------------ size-independent properties
 
-def test_large_batch_roundtrip_and_sampled_oracle(codec, oracle):
+def test_large_batch_roundtrip_and_sampled_oracle(codec, oracle, decode_form):
     """256 MiB of corpus (4096 blocks): every block status OK, decode(encode(x)) == x on the
     device, and a strided sample of blocks is byte-identical to the oracle."""
     import torch
