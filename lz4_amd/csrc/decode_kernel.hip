@@ -414,6 +414,7 @@ constexpr uint32_t kFarMax = 320;           // bytes per match the out-of-buffer
 #endif
 constexpr uint32_t kPrioT[3] = {LZ4MI_PRIO_T};  // compressed bytes left from which a block runs at issue priority 3, 2, 1
 constexpr uint32_t kPrio3 = kPrioT[0], kPrio2 = kPrioT[1], kPrio1 = kPrioT[2];
+constexpr uint32_t kHelpMin = 1024;         // compressed bytes left from which a block is worth a second wavefront
 constexpr uint32_t kTl = 136;               // token list entries (two bytes each): 64 tokens, a spare, the dummy slot at 128
 static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at least one sequence");
 static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
@@ -586,7 +587,8 @@ struct SeqLane {       // lane j: sequence j
 };
 
 // lo = lowest output position the buffer holds when the batch is copied, fl = output in front of this
-// position is in memory by then.
+// position is in memory by then.  BATCH = most output bytes of the batch.
+template <uint32_t BATCH>
 __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src, uint32_t in_end, uint32_t ip, uint32_t op,
                                                  uint32_t cap, uint32_t back_limit, int32_t lo, uint32_t fl, lds_u8 *cw,
                                                  lds_u16 *tl, uint32_t lane, ParseCtx &pc, SeqLane &q) {
@@ -607,7 +609,7 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
   bool dense = pc.dense;
   uint32_t shortrun = pc.shortrun;
-  while (count < kWave && tot <= kBatchOut - 512u) {
+  while (count < kWave && tot <= BATCH - 512u) {
     if (dense && count <= kWave - 22u) {
       const uint32_t t4 = cw32(cw, a + lane);
       const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
@@ -698,13 +700,13 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   // not yet in memory (possible right after the general loop): general loop
   const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
   const uint64_t realm = nreal < kWave ? (1ull << nreal) - 1ull : ~0ull;
-  const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > kBatchOut) & realm;
+  const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > BATCH) & realm;
   const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
   const uint32_t nover = overm ? (uint32_t)__builtin_ctzll(overm) : kWave;
   uint32_t nb = nreal;
   if (nbad < nb || nover < nb) {  // a sequence that fails a check, or the batch is full
     nb = nbad < nover ? nbad : nover;
-    bp.general = nbad <= nover;
+    bp.general = nbad <= nover || nb == 0u;  // a first sequence that is a batch of its own and more: general loop
     pc.have_win = true;
     bp.ip_stop = (uint32_t)wb + rdlane(ta, nb);
   } else if (nreal < count && nnok <= nbrk) {  // a token that is not for the batch
@@ -934,12 +936,33 @@ __device__ __forceinline__ void prio_by_left(uint32_t left) {
 #endif
 }
 
+// Where a block stands between two batches: enough for a second wavefront to join in (decode_block_pair).
+struct BlockState {
+  uint32_t ip, op;   // compressed and output position of the next batch
+  uint32_t fl;       // output in front of this position is in memory; [fl, op) is in the buffer only
+  uint32_t sneg;     // buffer offset of position p is p + sneg
+  int32_t vlo;       // the buffer holds output positions [max(vlo, -sneg), op)
+};
+constexpr int32_t kHandOver = -2;  // not a status: decode_block stopped between two batches for a helper to join
+
+// The two wavefronts of a workgroup that decode a block each: the one that runs out of blocks offers its help,
+// the other takes the offer between two batches and publishes where its block stands.
+struct HelpShared {
+  uint32_t offer[2];   // wavefront w has nothing left to do
+  uint32_t accept;     // 1 + w: wavefront w took the other one's offer
+  uint32_t block;      // its block
+  uint32_t state[5];   // BlockState
+};
+typedef __attribute__((address_space(3))) HelpShared lds_help;
+
 // One wavefront per block, batch after batch: the form for launches that fill the chip (sixteen blocks per CU).
+// With `help`: looks for the other wavefront's offer between two batches and returns kHandOver (state in bs, pc).
 template <bool STRICT, bool HAS_PREFIX>
 __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                 const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                 const uint8_t *__restrict__ prefix, uint32_t prefix_len,
-                                                lds_u8 *stg, lds_u8 *cw, lds_u16 *tl, uint32_t lane, uint32_t &out_len) {
+                                                lds_u8 *stg, lds_u8 *cw, lds_u16 *tl, uint32_t lane, uint32_t &out_len,
+                                                lds_help *help, uint32_t other, BlockState &bs, ParseCtx &pc) {
   const uint32_t in_end = src_len;
   uint8_t *const out = dst + op_start;
   const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
@@ -947,7 +970,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   uint32_t fl = 0;          // output in front of this position is in memory; [fl, op) is in the buffer only
   int32_t vlo = 0;          // the buffer holds output positions [max(vlo, sbase), op)
   uint32_t sneg = kH + goff;  // buffer offset of position p is p + sneg (sneg = -sbase)
-  ParseCtx pc = {0, 0, false, false, 0};
+  pc = ParseCtx{0, 0, false, false, 0};
   int32_t st = LZ4MI_OK;
 
   for (;;) {
@@ -960,9 +983,14 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
         stg_slide(stg, shift, kH + 16u, lane);
         sneg -= shift;
       }
+      if (help && in_end - ip >= kHelpMin && uni(help->offer[other])) {
+        bs = BlockState{ip, op, fl, sneg, vlo};
+        out_len = op;
+        return kHandOver;
+      }
       SeqLane q;
       const int32_t lo = vlo > -(int32_t)sneg ? vlo : -(int32_t)sneg;  // lowest position the buffer holds
-      const BatchPlan bp = parse_batch(src, in_end, ip, op, cap, back_limit, lo, fl, cw, tl, lane, pc, q);
+      const BatchPlan bp = parse_batch<kBatchOut>(src, in_end, ip, op, cap, back_limit, lo, fl, cw, tl, lane, pc, q);
       general = bp.general;
       if (bp.nb) {
         copy_far<HAS_PREFIX, kStgBytes>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
@@ -1006,22 +1034,24 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 // been written to memory.  The general loop runs on the copier with the parser waiting, and hands the state back
 // through `ctl`.
 
-template <bool STRICT, bool HAS_PREFIX>
+// BATCH = most output bytes of a batch, D = size of the buffer (kH + 16 + 2 * BATCH + 16).  The block starts at `start`
+// (its first byte, or where a wavefront on its own had got to: then pc is that wavefront's parse state).
+template <bool STRICT, bool HAS_PREFIX, uint32_t BATCH, uint32_t D>
 __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                      const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                      const uint8_t *__restrict__ prefix, uint32_t prefix_len,
                                                      lds_u8 *stg, lds_u8 *cw, lds_u16 *tl,
                                                      __attribute__((address_space(3))) PairShared *sh, uint32_t role,
-                                                     uint32_t lane, uint32_t &out_len) {
+                                                     uint32_t lane, uint32_t &out_len, const BlockState start, ParseCtx pc) {
+  static_assert(D == kH + 16 + 2 * BATCH + 16, "layout");
   const uint32_t in_end = src_len;
   uint8_t *const out = dst + op_start;
   const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
   // both wavefronts keep the same picture: the batch that is being copied starts at (ip, op), fl and the layout
   // (sneg, vlo) are the copier's
-  uint32_t ip = 0, op = 0, fl = 0;
-  int32_t vlo = 0;
-  uint32_t sneg = kH + goff;
-  ParseCtx pc = {0, 0, false, false, 0};
+  uint32_t ip = start.ip, op = start.op, fl = start.fl;
+  int32_t vlo = start.vlo;
+  uint32_t sneg = start.sneg;
   int32_t st = LZ4MI_OK;
   PH_DECL
 
@@ -1051,9 +1081,9 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
           q.dist = sh->desc[cur][3][lane];
           if (lane >= nb) { q.ml = 0; q.far = false; q.dist = 1; }
           prio_by_left(in_end - ip);
-          copy_far<HAS_PREFIX, kStgPair>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
+          copy_far<HAS_PREFIX, D>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
           PH(2);
-          copy_matches<kStgPair>(stg, sneg, nb, q, lane);
+          copy_matches<D>(stg, sneg, nb, q, lane);
           PH(3);
         }
         (void)stg_flush(stg, out, sneg, fl, b1, false, lane);  // ends at fl_next
@@ -1067,11 +1097,11 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
           const int32_t lo = vlo > -(int32_t)sneg_next ? vlo : -(int32_t)sneg_next;
           uint32_t at = ip_stop;
           do {
-            bp = parse_batch(src, in_end, at, b1, cap, back_limit, lo, fl_next, cw, tl, lane, pc, q);
+            bp = parse_batch<BATCH>(src, in_end, at, b1, cap, back_limit, lo, fl_next, cw, tl, lane, pc, q);
             at = bp.ip_stop;
           } while (!bp.nb && !bp.general);
           PH(5);
-          if (bp.nb) copy_literals<kStgPair>(cw, stg, sneg, q, lane);  // the buffer stands as the batch being copied needs it
+          if (bp.nb) copy_literals<D>(cw, stg, sneg, q, lane);  // the buffer stands as the batch being copied needs it
           PH(6);
         }
         if (bp.nb) {
@@ -1141,26 +1171,41 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
   return st;
 }
 
-// One wavefront per workgroup: a wavefront's LDS (ring + window) is then the unit the hardware
-// packs into a CU's 160 KiB.
+__device__ __forceinline__ BlockState block_start(const uint8_t *out) {
+  return BlockState{0, 0, 0, kH + (uint32_t)((uintptr_t)out & 15u), 0};
+}
+
+// Two wavefronts per workgroup, a block each (a wavefront's buffers are what the hardware packs: sixteen wavefronts
+// per CU).  A launch ends with its slowest block, so a wavefront that finds the queue empty does not leave: it
+// offers its help, and the other one, between two batches of its last block, takes it.  From there on the two share
+// that block as decode_block_pair does, in the two buffers taken together.
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgAlloc];
-  __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
-  __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[2][kStgAlloc];
+  __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][kCw + kCwPad];
+  __shared__ __attribute__((aligned(16))) uint16_t s_tl[2][kTl];
+  __shared__ HelpShared s_help;
+  static_assert(kStgPairAlloc % 16 == 0 && kStgPairAlloc + sizeof(PairShared) <= 2 * kStgAlloc, "the pair's buffer and shared words fit the two buffers");
   const uint32_t lane = lane_id();
-  lds_u8 *stg = (lds_u8 *)s_stg;
-  lds_u8 *cw = (lds_u8 *)s_cw;
-  lds_u16 *tl = (lds_u16 *)s_tl;
+  const uint32_t wave = uni(threadIdx.x / kWave);
+  lds_help *help = (lds_help *)&s_help;
+  if (threadIdx.x < 3) ((lds_u32 *)help)[threadIdx.x] = 0;  // offer[0], offer[1], accept
+  __syncthreads();
+  lds_u8 *stg = (lds_u8 *)s_stg[wave];
+  lds_u8 *cw = (lds_u8 *)s_cw[wave];
+  lds_u16 *tl = (lds_u16 *)s_tl[wave];
   // the decoder keeps the last 65536 bytes of a dictionary (lz4_frame_decoder.dart:278-282)
   const uint8_t *prefix = a.dict;
   const uint32_t prefix_len = a.dict_len;
   // When the launch has a wavefront for every block, a wavefront's block is its own index; larger
   // batches are handed out through the queue, where a wavefront's first block is still its own
   // index (thousands of wavefronts popping one queue head at launch serialise on it).
-  const uint32_t nwaves = gridDim.x;
+  const uint32_t nwaves = gridDim.x * 2;
   const bool direct = a.nblocks <= nwaves;
-  uint32_t b = uni(blockIdx.x);
+  BlockState bs = {0, 0, 0, 0, 0};
+  ParseCtx pc = {0, 0, false, false, 0};
+  bool handed = false;  // this wavefront took the other one's offer: its block goes on below
+  uint32_t b = uni(blockIdx.x * 2 + wave);
   for (;; b = direct ? 0xffffffffu : nwaves + next_block(counter, lane)) {
     if (b >= a.nblocks) break;
     if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
@@ -1180,12 +1225,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       out_len = stored;
     } else {
       st = decode_block<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg, cw, tl, lane,
-                                            out_len);
+#ifdef LZ4MI_NO_HELP
+                                            out_len, nullptr, wave ^ 1u, bs, pc);
+#else
+                                            out_len, help, wave ^ 1u, bs, pc);
+#endif
+      if (st == kHandOver) {
+        handed = true;
+        break;
+      }
     }
 #ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (lane == 0) {
+      a.out_len[b] = out_len;
+      a.status[b] = st;
+    }
+  }
+  // ---- out of blocks, or holding one that the other wavefront will help with
+  if (handed) {
+    if (lane == 0) {
+      help->accept = 1u + wave;
+      help->block = b;
+      help->state[0] = bs.ip; help->state[1] = bs.op; help->state[2] = bs.fl; help->state[3] = bs.sneg;
+      help->state[4] = (uint32_t)bs.vlo;
+    }
+  } else if (lane == 0) {
+    help->offer[wave] = 1u;
+  }
+  __syncthreads();
+  const uint32_t acc = uni(help->accept);
+  if (!acc) return;  // both are out of blocks
+  const uint32_t owner = acc - 1u;  // the block is the owner's and lives in its buffers; the owner goes on parsing
+  b = uni(help->block);
+  bs = BlockState{uni(help->state[0]), uni(help->state[1]), uni(help->state[2]), uni(help->state[3]), (int32_t)uni(help->state[4])};
+  {
+    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
+    const uint32_t src_len = uni(block_src_len(a, b));
+    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
+    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    const uint32_t role = wave == owner ? 0u : 1u;
+    // The pair's buffer (two batches behind the history) is the two wavefronts' buffers taken together, from the
+    // first one's start; the pair's shared words sit behind it.  A block of the second wavefront moves there first
+    // (what a buffer holds between two batches is its history: less than kH + 32 bytes).
+    lds_u8 *pstg = (lds_u8 *)s_stg[0];
+    if (owner == 1u) {
+      if (wave == 0u) {
+        for (uint32_t c = lane; c < (kH + 32u) / 16u; c += kWave) *(lds_u128 *)(pstg + 16u * c) = *(const lds_u128 *)((lds_u8 *)s_stg[1] + 16u * c);
+      }
+      __syncthreads();
+    }
+    lds_pair *sh = (lds_pair *)(pstg + kStgPairAlloc);
+    uint32_t out_len = 0;
+    const int32_t st = decode_block_pair<STRICT, HAS_PREFIX, kBatchOut, kStgPair>(
+        src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, pstg, (lds_u8 *)s_cw[owner],
+        (lds_u16 *)s_tl[owner], sh, role, lane, out_len, bs, pc);
+#ifdef LZ4MI_DEC_SPANS
+    if (role == 1 && lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (role == 1 && lane == 0) {
       a.out_len[b] = out_len;
       a.status[b] = st;
     }
@@ -1235,8 +1334,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       vm_quiesce();
       out_len = stored;
     } else {
-      st = decode_block_pair<STRICT, HAS_PREFIX>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len, stg, cw, tl, sh,
-                                                 role, lane, out_len);
+      st = decode_block_pair<STRICT, HAS_PREFIX, kBatchOut, kStgPair>(src, src_len, dst, 0, cap, prefix_len, prefix, prefix_len,
+                                                                     stg, cw, tl, sh, role, lane, out_len, block_start(dst),
+                                                                     ParseCtx{0, 0, false, false, 0});
     }
 #ifdef LZ4MI_DEC_SPANS
     if (role == 1 && lane == 0 && b < 65536) g_dec_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1288,8 +1388,9 @@ __global__ __launch_bounds__(128) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block_pair<false, true>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, tl, sh,
-                                          role, lane, produced);
+      st = decode_block_pair<false, true, kBatchOut, kStgPair>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len,
+                                                               stg, cw, tl, sh, role, lane, produced,
+                                                               block_start(c.dst + start), ParseCtx{0, 0, false, false, 0});
     }
     if (role == 1 && lane == 0) {
       c.out_len[b] = produced;
@@ -1397,8 +1498,8 @@ static uint32_t resident_per_cu(K kernel, int threads) {
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
                    uint32_t cu_count, hipStream_t s) {
   // as many workgroups as stay resident (one that is not would hold its first block back)
-  static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>, 64), resident_per_cu(decode_kernel<false, true>, 64),
-                                     resident_per_cu(decode_kernel<true, false>, 64), resident_per_cu(decode_kernel<true, true>, 64)};
+  static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>, 128), resident_per_cu(decode_kernel<false, true>, 128),
+                                     resident_per_cu(decode_kernel<true, false>, 128), resident_per_cu(decode_kernel<true, true>, 128)};
   static const uint32_t pair_per_cu[4] = {
       resident_per_cu(decode_pair_kernel<false, false>, 128), resident_per_cu(decode_pair_kernel<false, true>, 128),
       resident_per_cu(decode_pair_kernel<true, false>, 128), resident_per_cu(decode_pair_kernel<true, true>, 128)};
@@ -1411,13 +1512,16 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
   const bool pre = a.dict_len != 0;
   const uint32_t v = (strict ? 2 : 0) + (pre ? 1 : 0);
   // Few blocks (every one gets a resident pair of wavefronts): two wavefronts per block, each block done sooner.
-  // More blocks than that: one wavefront per block, twice as many blocks in flight.
+  // More blocks than that: one wavefront per block, twice as many blocks in flight, and a second one for the
+  // blocks that are still running when the queue is empty.
   const bool pair = form_env ? form_env == 2 : a.nblocks <= cu_count * pair_per_cu[v];
-  const uint32_t slots = cu_count * (pair ? pair_per_cu[v] : per_cu[v]);
-  const uint32_t grid = a.nblocks < slots ? a.nblocks : slots;
-  if (order && a.nblocks > grid) {  // only a queued launch has an order to choose
+  const uint32_t per_wg = pair ? 1u : 2u;  // blocks a workgroup of two wavefronts works on at a time
+  const uint32_t slots = cu_count * (pair ? pair_per_cu[v] : per_cu[v]) * per_wg;
+  const uint32_t inflight = a.nblocks < slots ? a.nblocks : slots;
+  const uint32_t grid = (inflight + per_wg - 1u) / per_wg;
+  if (order && a.nblocks > grid * per_wg) {  // only a queued launch has an order to choose
     // few blocks per wavefront: the launch ends with its slowest block, heavy blocks go first
-    uint32_t mix = a.nblocks >= kMixFromRounds * grid ? kMix : 0u;
+    uint32_t mix = a.nblocks >= kMixFromRounds * grid * per_wg ? kMix : 0u;
     if (mix_env >= 0) mix = (uint32_t)mix_env;
     uint32_t *tag = order + a.nblocks;
     const dim3 g((a.nblocks + 255) / 256), blk(256);
@@ -1426,7 +1530,7 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
   } else {
     order = nullptr;
   }
-  dim3 g(grid), blk(pair ? 128 : 64);
+  dim3 g(grid), blk(128);
   if (pair) {
     if (strict) {
       if (pre) hipLaunchKernelGGL((decode_pair_kernel<true, true>), g, blk, 0, s, a, counter, order);
