@@ -208,7 +208,8 @@ __device__ __forceinline__ void pair_copy(lds_pair *sh, uint8_t *dst, const uint
                     : lane == 4 ? (uint32_t)(g >> 32) : h;
   }
   __syncthreads();
-  wave_copy(dst + h, src + h, n - h, lane);
+  if (n - h >= kCopyLong) wave_copy_long(dst + h, src + h, n - h, lane);
+  else wave_copy(dst + h, src + h, n - h, lane);
   vm_quiesce();
   __syncthreads();
 }
@@ -219,7 +220,9 @@ __device__ __forceinline__ void pair_serve(lds_pair *sh, uint32_t lane) {
     if (uni(sh->req[0]) == kReqEnd) break;
     uint8_t *dst = (uint8_t *)(uintptr_t)(((uint64_t)uni(sh->req[2]) << 32) | uni(sh->req[1]));
     const uint8_t *src = (const uint8_t *)(uintptr_t)(((uint64_t)uni(sh->req[4]) << 32) | uni(sh->req[3]));
-    wave_copy(dst, src, uni(sh->req[5]), lane);
+    const uint32_t n = uni(sh->req[5]);
+    if (n >= kCopyLong) wave_copy_long(dst, src, n, lane);
+    else wave_copy(dst, src, n, lane);
     vm_quiesce();
     __syncthreads();
   }
@@ -309,7 +312,8 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         if (PAIR && lit >= kPairCopyMin) {
           pair_copy(sh, out + op, src + ip, lit, lane);
         } else {
-          wave_copy(out + op, src + ip, lit, lane);
+          if (lit >= kCopyLong) wave_copy_long(out + op, src + ip, lit, lane);
+          else wave_copy(out + op, src + ip, lit, lane);
           vm_quiesce();
         }
         rlo = op + lit;  // ring holds nothing older than this
@@ -925,6 +929,11 @@ __device__ __forceinline__ int32_t stg_restore(lds_u8 *stg, uint8_t *out, uint32
   return (int32_t)(16u * cmin) - sn;
 }
 
+// Compressed to 15/16 of its output or more: (nearly) nothing but literals.
+__device__ __forceinline__ bool literal_block(uint32_t src_len, uint32_t cap) {
+  return (uint64_t)src_len * 16u >= (uint64_t)cap * 15u;
+}
+
 // Longest remaining work first: the wavefronts of a SIMD compete for its issue slots, and a launch
 // ends with its slowest block.  What is left of the compressed block stands for the work left.
 __device__ __forceinline__ void prio_by_left(uint32_t left) {
@@ -972,10 +981,13 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
   uint32_t sneg = kH + goff;  // buffer offset of position p is p + sneg (sneg = -sbase)
   pc = ParseCtx{0, 0, false, false, 0};
   int32_t st = LZ4MI_OK;
+  // A block that is hardly shorter than its output starts with a long literal run (often it is nothing else):
+  // its first sequence goes straight to the general loop, without a window and a parse in front of the copy.
+  bool lit_first = literal_block(src_len, cap);
 
   for (;;) {
     bool general = true;
-    if (in_end - ip >= 8u) {
+    if (in_end - ip >= 8u && !lit_first) {
       prio_by_left(in_end - ip);
       // ---- slide the buffer so that the batch starts right behind kH bytes of history
       const uint32_t shift = (op + sneg - kH) & ~15u;  // op + sneg >= kH always
@@ -1002,6 +1014,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       }
       ip = bp.ip_stop;
     }
+    lit_first = false;
     if (!general) continue;
 
     // ---- one sequence through the general loop (and every end of a block)
@@ -1053,12 +1066,14 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
   int32_t vlo = start.vlo;
   uint32_t sneg = start.sneg;
   int32_t st = LZ4MI_OK;
+  bool lit_first = start.ip == 0u && literal_block(src_len, cap);  // the first sequence goes straight to the general loop
   PH_DECL
 
   for (;;) {
     // ---- fill: behind the block's start or the general loop the pipeline starts with a batch of nothing, so the
     // parser makes the first real one with nobody copying yet.  The layout stands as that batch needs it (no slide).
-    if (role == 0 && lane < 4) sh->hdr[0][lane] = lane == 1 ? op : lane == 2 ? ip : 0u;
+    if (role == 0 && lane < 4) sh->hdr[0][lane] = lane == 1 ? op : lane == 2 ? ip : lane == 3 && lit_first ? 1u : 0u;
+    lit_first = false;
     PH(0);
     __syncthreads();
     PH(1);
@@ -1171,6 +1186,38 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
   return st;
 }
 
+// What a block's decode needs, fetched in one memory round trip: lane k loads the k-th per-block word (the arrays a
+// launch does not use cost nothing), one wait, cross-lane reads.  Literal-only blocks are short enough for a chain of
+// dependent loads in front of each of them to show.
+struct BlockParams {
+  const uint8_t *src;
+  uint8_t *dst;
+  uint32_t src_len, cap, stored;
+};
+__device__ __forceinline__ BlockParams load_block_params(const BatchArgs &a, uint32_t b, uint32_t lane) {
+  uint32_t lo = 0, hi = 0;
+  if (lane == 0 && a.src_off) { const uint64_t v = a.src_off[b]; lo = (uint32_t)v; hi = (uint32_t)(v >> 32); }
+  if (lane == 1 && a.dst_off) { const uint64_t v = a.dst_off[b]; lo = (uint32_t)v; hi = (uint32_t)(v >> 32); }
+  if (lane == 2 && a.src_len) lo = a.src_len[b];
+  if (lane == 3 && a.dst_cap) lo = a.dst_cap[b];
+  if (lane == 4 && a.stored_len) lo = a.stored_len[b];
+  BlockParams p;
+  const uint64_t so = a.src_off ? ((uint64_t)rdlane(hi, 0) << 32) | rdlane(lo, 0) : (uint64_t)b * a.src_stride;
+  const uint64_t dof = a.dst_off ? ((uint64_t)rdlane(hi, 1) << 32) | rdlane(lo, 1) : (uint64_t)b * a.dst_stride;
+  p.src = a.src + so;
+  p.dst = a.dst + dof;
+  if (a.src_len) {
+    p.src_len = rdlane(lo, 2);
+  } else {
+    const uint64_t start = (uint64_t)b * a.src_len_uniform;
+    const uint64_t left = a.src_total > start ? a.src_total - start : 0;
+    p.src_len = left < a.src_len_uniform ? (uint32_t)left : a.src_len_uniform;
+  }
+  p.cap = a.dst_cap ? rdlane(lo, 3) : a.dst_cap_uniform;
+  p.stored = a.stored_len ? rdlane(lo, 4) : 0u;
+  return p;
+}
+
 __device__ __forceinline__ BlockState block_start(const uint8_t *out) {
   return BlockState{0, 0, 0, kH + (uint32_t)((uintptr_t)out & 15u), 0};
 }
@@ -1206,21 +1253,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   ParseCtx pc = {0, 0, false, false, 0};
   bool handed = false;  // this wavefront took the other one's offer: its block goes on below
   uint32_t b = uni(blockIdx.x * 2 + wave);
-  for (;; b = direct ? 0xffffffffu : nwaves + next_block(counter, lane)) {
+  for (;;) {
     if (b >= a.nblocks) break;
     if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
-    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
-    const uint32_t src_len = uni(block_src_len(a, b));
-    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    const BlockParams bp_ = load_block_params(a, b, lane);
+    const uint8_t *src = bp_.src;
+    const uint32_t src_len = bp_.src_len;
+    uint8_t *dst = bp_.dst;
+    const uint32_t cap = bp_.cap;
     uint32_t out_len = 0;
 #ifdef LZ4MI_DEC_SPANS
     if (lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     int32_t st = LZ4MI_OK;
-    const uint32_t stored = a.stored_len ? uni(a.stored_len[b]) : 0u;
+    const uint32_t stored = bp_.stored;
     if (stored) {  // a stored block rides in the same queue: its copy overlaps the issue-bound blocks
-      wave_copy(dst, src, stored, lane);
+      if (stored >= kCopyLong) wave_copy_long(dst, src, stored, lane);
+      else wave_copy(dst, src, stored, lane);
       vm_quiesce();
       out_len = stored;
     } else {
@@ -1242,6 +1291,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       a.out_len[b] = out_len;
       a.status[b] = st;
     }
+    if (direct) break;
+    b = nwaves + next_block(counter, lane);
   }
   // ---- out of blocks, or holding one that the other wavefront will help with
   if (handed) {
@@ -1261,10 +1312,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   b = uni(help->block);
   bs = BlockState{uni(help->state[0]), uni(help->state[1]), uni(help->state[2]), uni(help->state[3]), (int32_t)uni(help->state[4])};
   {
-    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
-    const uint32_t src_len = uni(block_src_len(a, b));
-    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    const BlockParams bp_ = load_block_params(a, b, lane);
+    const uint8_t *src = bp_.src;
+    const uint32_t src_len = bp_.src_len;
+    uint8_t *dst = bp_.dst;
+    const uint32_t cap = bp_.cap;
     const uint32_t role = wave == owner ? 0u : 1u;
     // The pair's buffer (two batches behind the history) is the two wavefronts' buffers taken together, from the
     // first one's start; the pair's shared words sit behind it.  A block of the second wavefront moves there first
@@ -1317,16 +1369,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   for (;;) {
     if (b >= a.nblocks) break;
     if (order) b = uni(order[b]);  // queue position -> block (long blocks first)
-    const uint8_t *src = a.src + uni64(a.src_off ? a.src_off[b] : (uint64_t)b * a.src_stride);
-    const uint32_t src_len = uni(block_src_len(a, b));
-    uint8_t *dst = a.dst + uni64(a.dst_off ? a.dst_off[b] : (uint64_t)b * a.dst_stride);
-    const uint32_t cap = uni(a.dst_cap ? a.dst_cap[b] : a.dst_cap_uniform);
+    const BlockParams bp_ = load_block_params(a, b, lane);
+    const uint8_t *src = bp_.src;
+    const uint32_t src_len = bp_.src_len;
+    uint8_t *dst = bp_.dst;
+    const uint32_t cap = bp_.cap;
     uint32_t out_len = 0;
 #ifdef LZ4MI_DEC_SPANS
     if (role == 1 && lane == 0 && b < 65536) g_dec_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     int32_t st = LZ4MI_OK;
-    const uint32_t stored = a.stored_len ? uni(a.stored_len[b]) : 0u;
+    const uint32_t stored = bp_.stored;
     if (stored) {  // a stored block rides in the same queue: its copy overlaps the issue-bound blocks
       const uint32_t half = (stored / 2u) & ~15u;
       if (role == 0) wave_copy(dst, src, half, lane);

@@ -112,6 +112,26 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
   if (h2) st128(d + off + 2048, r2);
 }
 
+// The same for copies of 16 KiB and more (a literal-only block, a stored block): 12 KiB in flight per round trip.
+// A function of its own, not inlined: its twelve 16-byte registers per lane would otherwise count against every
+// kernel that copies anything.
+__device__ __attribute__((noinline)) void wave_copy_long(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
+  const uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;
+  if (lane < head) dst[lane] = src[lane];
+  const uint8_t *s = src + head;
+  uint8_t *d = dst + head;
+  uint32_t off = 0;
+  for (; off + 12288 <= n - head; off += 12288) {
+    U128U v[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) v[k] = ld128(s + off + 16 * lane + 1024 * k);
+#pragma unroll
+    for (int k = 0; k < 12; k++) st128(d + off + 16 * lane + 1024 * k, v[k]);
+  }
+  wave_copy(d + off, s + off, n - head - off, lane);
+}
+constexpr uint32_t kCopyLong = 16384;
+
 // Inclusive prefix sum over the 64 lanes: row shifts inside the 16-lane rows, then the two row
 // broadcasts (lanes without a source add zero).
 template <int CTRL, int ROW_MASK>
