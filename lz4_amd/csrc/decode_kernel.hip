@@ -127,6 +127,50 @@ __device__ __forceinline__ bool read_ext(InWindow &w, Stream &s, uint32_t &ip, u
   }
 }
 
+// A long match with a short distance (a run of one byte, a short period repeated for kilobytes) is a pattern fill:
+// output byte k is byte k mod dist of the period in front of the match (byte_writer.dart:116-118).  The period goes
+// into LDS once, repeated far enough that any 16 bytes of the pattern lie in one piece, and every lane then builds
+// its 16-byte stores from there: stores only, no store of the match waits for a load of what it wrote before.
+// `pat` holds kPatPeriod + 32 bytes; the period [src_period, src_period + dist) is in memory.
+constexpr uint32_t kPatPeriod = 2048;  // longest distance filled this way
+constexpr uint32_t kPatMin = 1024;     // shortest match worth the set-up
+__device__ __forceinline__ void pattern_fill(uint8_t *dst, const uint8_t *src_period, uint32_t dist, uint32_t ml,
+                                             lds_u8 *pat, uint32_t lane) {
+  // pattern bytes [0, dist + 20): byte j is period byte j mod dist
+  {
+    uint32_t r = lane % dist;
+    const uint32_t step = kWave % dist;
+    for (uint32_t j = lane; j < dist + 20u; j += kWave) {
+      pat[j] = src_period[r];
+      r += step;
+      if (r >= dist) r -= dist;
+    }
+  }
+  const uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;  // ml >= kPatMin > head
+  if (lane < head) dst[lane] = src_period[lane % dist];
+  vm_quiesce();
+  const uint32_t body = (ml - head) & ~15u;
+  uint8_t *d = dst + head;
+  uint32_t r = (head + 16u * lane) % dist;  // where this lane's piece starts in the pattern
+  const uint32_t step = 1024u % dist;
+  for (uint32_t off = 16u * lane; off < body; off += 1024u) {
+    const lds_u32 *q = (const lds_u32 *)(pat + (r & ~3u));
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+    const uint32_t sh = r & 3u;
+    U128U v;
+    v.a = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    v.b = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    v.c = __builtin_amdgcn_alignbyte(w3, w2, sh);
+    v.d = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    st128(d + off, v);
+    r += step;
+    if (r >= dist) r -= dist;
+  }
+  const uint32_t tail = ml - head - body;
+  if (lane < tail) d[body + lane] = pat[(head + body + lane) % dist];
+  vm_quiesce();
+}
+
 template <bool HAS_PREFIX>
 __device__ __forceinline__ void copy_match(uint8_t *dst, uint64_t op, uint32_t dist, uint32_t ml,
                                            const uint8_t *__restrict__ prefix, uint32_t prefix_len,
@@ -379,12 +423,27 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
         vm_quiesce();
       }
       rlo = (uint32_t)ring_from;
+    } else if (dist <= kPatPeriod && ml >= kPatMin && (int64_t)(op_start + op) >= (int64_t)dist) {
+      // (the period lies in the output, not in the prefix; the ring holds nothing the general loop needs past this match)
+      pattern_fill(dst + op_start + op, dst + op_start + op - dist, dist, ml, ring, lane);
+      rlo = op + ml;
     } else {
       copy_match<HAS_PREFIX>(dst, op_start + op, dist, ml, prefix, prefix_len, lane);
       rlo = op + ml;
     }
     op += ml;
-    if (ONE) { st = kSwitchRun; break; }
+    if (ONE) {
+      // Back to the batch loop, unless the next sequence would come straight back: a literal run with eight or
+      // more length bytes (token, then seven bytes of 255) is not for a batch.
+      bool again = false;
+      if (in_end - ip >= 9u) {
+        if (ip - sm.sp + 8u > kWave) stream_load(w, sm, ip, lane);
+        const uint32_t rel = ip - sm.sp;
+        const uint64_t ff = ballot(sm.S == 255u) >> (rel + 1u);
+        again = (rdlane(sm.S, rel) >> 4) == 15u && (ff & 0x7full) == 0x7full;
+      }
+      if (!again) { st = kSwitchRun; break; }
+    }
   }
   in_used = ip;
   out_len = op;
