@@ -159,9 +159,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: what libraries print there (RCCL's version banner at
+    # communicator set-up) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     if args.config in (2, 4):
         from scripts.bench_configs import run_config
-        print(json.dumps(run_config(args)))
+        json_out.write(json.dumps(run_config(args)) + "\n")
+        json_out.flush()
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,7 +366,8 @@ def main():
             result["config"]["nonconformant_blocks_oracle"] = cb["nonconformant_blocks"]
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if multi:
         dist.barrier()
         dist.destroy_process_group()
