@@ -1,4 +1,4 @@
-// LZ4 block decoder for gfx950: one wavefront per block.
+// LZ4 block decoder for gfx950: one or two wavefronts per block.
 //
 // Follows lz4BlockDecompress (strict) and lz4BlockDecompressInto (lenient) of
 // lib/src/block/lz4_block_decoder.dart:7-119 with ByteWriter.copyMatch
@@ -8,19 +8,23 @@
 // Two loops share a block.
 //
 // The batch loop takes up to 64 sequences at a time.  The compressed bytes sit in an LDS window;
-// every lane parses the byte it stands on as if it were a token (lengths with up to two extension
-// bytes, offset, where the next token would start), and the chain of real token starts is followed
-// with one cross-lane read per sequence.  After that lane j owns sequence j: a prefix sum places
-// all sequences in the output, the reference's checks are evaluated for all of them at once, and
-// the copies run out of and into an LDS ring that mirrors the most recent output: literals lane
-// by lane, matches one after the other with the whole wavefront (LDS operations of a wavefront
-// execute in order, so a match sees everything written before it), matches older than the ring
-// four at a time out of memory.  The ring is written to memory in aligned 16-byte pieces once per
-// batch.  A sequence that does not fit this scheme (three or more length-extension bytes, the
-// last sequence of a block, anything that fails a check) ends the batch in front of it.
+// every lane parses the byte it stands on as if it were a token, and the chain of real token
+// starts is followed with one cross-lane read per sequence.  After that lane j owns sequence j: a
+// prefix sum places all sequences in the output, the reference's checks are evaluated for all of
+// them at once, and the copies run out of and into an LDS buffer that mirrors the most recent
+// output: literals lane by lane, matches one after the other with the whole wavefront (LDS
+// operations of a wavefront execute in order, so a match sees everything written before it),
+// matches older than the buffer four at a time out of memory.  The buffer is written to memory in
+// aligned 16-byte pieces once per batch.  A sequence that does not fit this scheme (eight or more
+// length-extension bytes, the last sequence of a block, anything that fails a check) ends the
+// batch in front of it.
 //
 // The general loop (decode_run) takes such a sequence on its own, straight from and to memory,
 // in the reference's order of checks, and is where every block ends: all status codes come from it.
+//
+// The batch is made of pieces (parse_batch, copy_literals, copy_far, copy_matches, stg_flush) that
+// one wavefront runs in turn (decode_block) or two share (decode_block_pair: one parses the next
+// batch and places its literals while the other copies the matches of the current one).
 #include <atomic>
 #include <cstdlib>
 
