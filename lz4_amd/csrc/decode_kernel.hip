@@ -475,7 +475,6 @@ constexpr uint32_t kLitMax = 15 + 6 * 255 + 254;  // longest literal run of a ba
 constexpr uint32_t kMatMax = 19 + 5 * 255 + 254;  // longest match (up to six extension bytes)
 constexpr uint32_t kSeqIn = 8 + kLitMax + 8 + 8;  // compressed bytes a batched sequence may span, plus slack
 constexpr uint32_t kSeqTyp = 320;           // a window with fewer bytes than this behind ip is not worth a parse
-constexpr uint32_t kFarMax = 320;           // bytes per match the out-of-buffer path fetches (5 steps of 64)
 #ifndef LZ4MI_PRIO_T
 #define LZ4MI_PRIO_T 12288, 8192, 4096
 #endif
@@ -763,9 +762,9 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   const bool good = incl <= cap - op && dist != 0u && (uint64_t)dist <= (uint64_t)o_mat + back_limit;
   const int32_t sp = (int32_t)o_mat - (int32_t)dist;  // match source (may lie in front of the block)
   bool far = mine && sp < lo;
-  // an out-of-buffer source that is longer than the fetch takes, or that reaches into output
-  // not yet in memory (possible right after the general loop): general loop
-  const bool bad = mine && (!good || (far && (ml > kFarMax || sp + (int32_t)ml > (int32_t)fl)));
+  // an out-of-buffer source that reaches into output not yet in memory (possible right after the general
+  // loop): general loop
+  const bool bad = mine && (!good || (far && sp + (int32_t)ml > (int32_t)fl));
   const uint64_t realm = nreal < kWave ? (1ull << nreal) - 1ull : ~0ull;
   const uint64_t badm = ballot(bad) & realm, overm = ballot(incl > BATCH) & realm;
   const uint32_t nbad = badm ? (uint32_t)__builtin_ctzll(badm) : kWave;
@@ -871,48 +870,48 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
   }
 }
 
-// ---- matches whose source is older than the buffer: fetched from memory, four per round trip
+// ---- matches whose source is older than the buffer: fetched from memory in pieces of up to 64 bytes (a byte per
+// lane), sixteen pieces per round trip whichever matches they belong to.  (Data with long distances, and every
+// linked block near its start, has most of its matches here: the round trips are what that costs.)
+constexpr uint32_t kFarPieces = 16;
 template <bool HAS_PREFIX, uint32_t D>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
                                          uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
-  for (uint64_t fm = ballot(q.far); fm;) {
-    int32_t fs[4];
-    uint32_t fd[4], fn[4];
+  uint64_t fm = ballot(q.far);
+  if (!fm) return;
+  int32_t cs = 0;            // the match being cut into pieces: source position, buffer offset, bytes left
+  uint32_t cd = 0, cn = 0;
+  for (;;) {
+    int32_t ps[kFarPieces];
+    uint32_t pd[kFarPieces], pn[kFarPieces];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; u++) {
-      fs[u] = 0; fd[u] = 0; fn[u] = 0;
-      if (fm) {
+    for (uint32_t u = 0; u < kFarPieces; u++) {
+      if (cn == 0 && fm) {
         const uint32_t j = (uint32_t)__builtin_ctzll(fm);
         fm &= fm - 1ull;
-        fs[u] = (int32_t)rdlane((uint32_t)q.sp, j);
-        fd[u] = rdlane(q.o_mat, j) + sneg;
-        fn[u] = rdlane(q.ml, j);
+        cs = (int32_t)rdlane((uint32_t)q.sp, j);
+        cd = rdlane(q.o_mat, j) + sneg;
+        cn = rdlane(q.ml, j);
+      }
+      const uint32_t n = cn < kWave ? cn : kWave;
+      ps[u] = cs; pd[u] = cd; pn[u] = n;
+      cs += (int32_t)n; cd += n; cn -= n;
+    }
+    if (pn[0] == 0) break;
+    uint32_t v[kFarPieces];
+#pragma unroll
+    for (uint32_t u = 0; u < kFarPieces; u++) {
+      v[u] = 0;
+      if (pn[u]) {  // lanes past the end read the last byte again
+        const int64_t ap = (int64_t)op_start + ps[u] + (int64_t)(lane < pn[u] ? lane : pn[u] - 1u);
+        v[u] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
       }
     }
-    uint32_t v[4][kFarMax / kWave];
 #pragma unroll
-    for (uint32_t u = 0; u < 4; u++) {
-#pragma unroll
-      for (uint32_t t = 0; t < kFarMax / kWave; t++) {
-        v[u][t] = 0;
-        if (t * kWave < fn[u]) {  // lanes past the end read the last byte again
-          const uint32_t idx = t * kWave + lane < fn[u] ? t * kWave + lane : fn[u] - 1u;
-          const int64_t ap = (int64_t)op_start + fs[u] + (int64_t)idx;
-          v[u][t] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
-        }
-      }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4; u++) {
-#pragma unroll
-      for (uint32_t t = 0; t < kFarMax / kWave; t++) {
-        if (t * kWave < fn[u]) {
-          const uint32_t idx = t * kWave + lane;
-          stg[idx < fn[u] ? fd[u] + idx : D + lane] = (uint8_t)v[u][t];
-        }
-      }
-    }
+    for (uint32_t u = 0; u < kFarPieces; u++)
+      if (pn[u]) stg[lane < pn[u] ? pd[u] + lane : D + lane] = (uint8_t)v[u];
     vm_quiesce();
+    if (cn == 0 && !fm) break;
   }
 }
 
