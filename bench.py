@@ -177,13 +177,35 @@ def main():
     # LZ4MI_BENCH_DIST=1 takes the multi-rank code path (RCCL init, size exchange, frame assembly) with one
     # rank, to rehearse it on a one-GPU box
     multi = world > 1 or os.environ.get("LZ4MI_BENCH_DIST") == "1" or args.config == 3
+    # LZ4MI_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges through gloo (RCCL takes one rank per device):
+    # a rehearsal of the rank > 0 code path on a one-GPU box, not a measurement
+    one_gpu = os.environ.get("LZ4MI_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+            # gloo exchanges host tensors: stage the two collectives the step uses through the host
+            _ag, _ar = dist.all_gather_into_tensor, dist.all_reduce
+
+            def _ag_host(out, inp, group=None):
+                torch.cuda.current_stream().synchronize()
+                o = torch.empty(out.shape, dtype=out.dtype)
+                _ag(o, inp.cpu(), group=group)
+                out.copy_(o)
+
+            def _ar_host(t, op=dist.ReduceOp.SUM, group=None):
+                c = t.cpu()
+                _ar(c, op=op, group=group)
+                t.copy_(c)
+            dist.all_gather_into_tensor, dist.all_reduce = _ag_host, _ar_host
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
     else:
         torch.cuda.set_device(0)
@@ -258,6 +280,8 @@ def main():
 
     for _ in range(args.warmup):
         step(False)
+        if one_gpu:
+            print(f"rank {rank}: warm-up step done", file=sys.stderr, flush=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -292,6 +316,8 @@ def main():
         assert int(keep["body_end"]) == int(starts[-1] + allrec[-1])
         assert int(keep["total"]) == world * nb * BLOCK
         extra["ranks_seen_by_rccl"] = dist.get_world_size()
+        if one_gpu:
+            extra["rehearsal"] = "every rank on GPU 0, exchange through gloo: not a measurement"
         extra["frame_bytes"] = int(keep["body_end"]) + 4
         if rank == 0:  # this rank's window against the oracle's frame of the same blocks, byte for byte
             from oracle import lz4ref
