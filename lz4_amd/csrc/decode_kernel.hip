@@ -964,31 +964,35 @@ __device__ __forceinline__ void stg_slide(lds_u8 *stg, uint32_t shift, uint32_t 
   }
 }
 
-// Behind the general loop (which used the buffer for itself): brings back the history, kH bytes of this
-// block's output in whole aligned 16-byte pieces, under the layout sneg.  Returns the lowest position held.
-__device__ __forceinline__ int32_t stg_restore(lds_u8 *stg, uint8_t *out, uint32_t op, uint32_t sneg, uint32_t lane) {
+// Behind the general loop (which used the buffer for itself), or at the start of a linked block: brings back the
+// history, up to H bytes of output in front of position op in whole aligned 16-byte pieces, under the layout sneg.
+// Nothing in front of position min_pos is read (0: the block's own output; a linked block's history goes on into
+// the blocks in front of it).  Returns the lowest position held.
+template <uint32_t H>
+__device__ __forceinline__ int32_t stg_restore(lds_u8 *stg, uint8_t *out, uint32_t op, uint32_t sneg, int32_t min_pos, uint32_t lane) {
   // piece c holds positions [16c - sneg, 16c - sneg + 16); the last piece that holds a byte of output is
   // the one of position op - 1
-  const uint32_t last = (op - 1u + sneg) >> 4;  // <= kH / 16
-  // lowest piece that lies inside the block's output
-  const int32_t sn = (int32_t)sneg;
+  const uint32_t last = (op - 1u + sneg) >> 4;  // <= H / 16
+  // lowest piece that lies inside the output that exists
+  const int32_t sn = (int32_t)sneg + min_pos;  // buffer offset of position min_pos
   const uint32_t cmin = sn > 0 ? (uint32_t)(sn + 15) >> 4 : 0u;
-  static_assert(kH == 4096, "five pieces per lane");
   const u32x4 z = {0, 0, 0, 0};
-  const uint32_t c0 = lane, c1 = kWave + lane, c2 = 2 * kWave + lane, c3 = 3 * kWave + lane, c4 = 4 * kWave + lane;
-  const uint8_t *g = out - sn;
-  const u32x4 v0 = c0 <= last && c0 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c0) : z;
-  const u32x4 v1 = c1 <= last && c1 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c1) : z;
-  const u32x4 v2 = c2 <= last && c2 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c2) : z;
-  const u32x4 v3 = c3 <= last && c3 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c3) : z;
-  const u32x4 v4 = c4 <= last && c4 >= cmin ? *(const u32x4 *)(g + 16 * (int32_t)c4) : z;
-  if (c0 <= last) *(lds_u128 *)(stg + 16u * c0) = v0;
-  if (c1 <= last) *(lds_u128 *)(stg + 16u * c1) = v1;
-  if (c2 <= last) *(lds_u128 *)(stg + 16u * c2) = v2;
-  if (c3 <= last) *(lds_u128 *)(stg + 16u * c3) = v3;
-  if (c4 <= last) *(lds_u128 *)(stg + 16u * c4) = v4;
+  const uint8_t *g = out - (int32_t)sneg;
+  for (uint32_t b0 = cmin; b0 <= last; b0 += 5 * kWave) {  // five pieces per lane and round trip (all of H = 4096)
+    const uint32_t c0 = b0 + lane, c1 = c0 + kWave, c2 = c0 + 2 * kWave, c3 = c0 + 3 * kWave, c4 = c0 + 4 * kWave;
+    const u32x4 v0 = c0 <= last ? *(const u32x4 *)(g + 16 * (int32_t)c0) : z;
+    const u32x4 v1 = c1 <= last ? *(const u32x4 *)(g + 16 * (int32_t)c1) : z;
+    const u32x4 v2 = c2 <= last ? *(const u32x4 *)(g + 16 * (int32_t)c2) : z;
+    const u32x4 v3 = c3 <= last ? *(const u32x4 *)(g + 16 * (int32_t)c3) : z;
+    const u32x4 v4 = c4 <= last ? *(const u32x4 *)(g + 16 * (int32_t)c4) : z;
+    if (c0 <= last) *(lds_u128 *)(stg + 16u * c0) = v0;
+    if (c1 <= last) *(lds_u128 *)(stg + 16u * c1) = v1;
+    if (c2 <= last) *(lds_u128 *)(stg + 16u * c2) = v2;
+    if (c3 <= last) *(lds_u128 *)(stg + 16u * c3) = v3;
+    if (c4 <= last) *(lds_u128 *)(stg + 16u * c4) = v4;
+  }
   vm_quiesce();
-  return (int32_t)(16u * cmin) - sn;
+  return (int32_t)(16u * cmin) - (int32_t)sneg;
 }
 
 // Compressed to 15/16 of its output or more: (nearly) nothing but literals.
@@ -1090,7 +1094,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
     if (st != kSwitchRun) break;
     sneg = kH + ((op + goff) & 15u) - op;
     vlo = (int32_t)op;
-    if (in_end - ip >= 8u && op > 0) vlo = stg_restore(stg, out, op, sneg, lane);
+    if (in_end - ip >= 8u && op > 0) vlo = stg_restore<kH>(stg, out, op, sneg, 0, lane);
   }
 #ifndef LZ4MI_NO_PRIO
   __builtin_amdgcn_s_setprio(0);
@@ -1109,16 +1113,19 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
 // been written to memory.  The general loop runs on the copier with the parser waiting, and hands the state back
 // through `ctl`.
 
-// BATCH = most output bytes of a batch, D = size of the buffer (kH + 16 + 2 * BATCH + 16).  The block starts at `start`
-// (its first byte, or where a wavefront on its own had got to: then pc is that wavefront's parse state).
-template <bool STRICT, bool HAS_PREFIX, uint32_t BATCH, uint32_t D>
+// BATCH = most output bytes of a batch, H = bytes of history the buffer keeps, D = size of the buffer
+// (H + 16 + 2 * BATCH + 16).  The block starts at `start` (its first byte, or where a wavefront on its own had got to:
+// then pc is that wavefront's parse state).  LINKED: the output in front of the block (back to position -hist_len)
+// is history too, and the buffer starts with the last H bytes of it.
+template <bool STRICT, bool HAS_PREFIX, uint32_t BATCH, uint32_t D, uint32_t H = kH, bool LINKED = false>
 __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__ src, uint32_t src_len, uint8_t *dst,
                                                      const uint64_t op_start, uint32_t cap, uint32_t back_limit,
                                                      const uint8_t *__restrict__ prefix, uint32_t prefix_len,
                                                      lds_u8 *stg, lds_u8 *cw, lds_u16 *tl,
                                                      __attribute__((address_space(3))) PairShared *sh, uint32_t role,
-                                                     uint32_t lane, uint32_t &out_len, const BlockState start, ParseCtx pc) {
-  static_assert(D == kH + 16 + 2 * BATCH + 16, "layout");
+                                                     uint32_t lane, uint32_t &out_len, const BlockState start, ParseCtx pc,
+                                                     uint32_t hist_len = 0) {
+  static_assert(D == H + 16 + 2 * BATCH + 16 && D + 80 <= 65536, "layout");
   const uint32_t in_end = src_len;
   uint8_t *const out = dst + op_start;
   const uint32_t goff = (uint32_t)((uintptr_t)out & 15u);
@@ -1129,7 +1136,16 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
   uint32_t sneg = start.sneg;
   int32_t st = LZ4MI_OK;
   bool lit_first = start.ip == 0u && literal_block(src_len, cap);  // the first sequence goes straight to the general loop
+  const int32_t min_pos = LINKED ? -(int32_t)hist_len : 0;  // lowest position that is output of this frame
   PH_DECL
+  if (LINKED && hist_len && !lit_first) {
+    // the copying wavefront wrote that output (this block's predecessors ran on the same two wavefronts)
+    int32_t lo = 0;
+    if (role == 1) lo = stg_restore<H>(stg, out, 0u, sneg, min_pos, lane);
+    const int32_t sn = (int32_t)sneg + min_pos;
+    vlo = (int32_t)(16u * (sn > 0 ? (uint32_t)(sn + 15) >> 4 : 0u)) - (int32_t)sneg;  // what stg_restore returns
+    (void)lo;
+  }
 
   for (;;) {
     // ---- fill: behind the block's start or the general loop the pipeline starts with a batch of nothing, so the
@@ -1144,7 +1160,7 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
       const uint32_t nb = uni(sh->hdr[cur][0]), b1 = uni(sh->hdr[cur][1]), ip_stop = uni(sh->hdr[cur][2]);
       const bool stop = uni(sh->hdr[cur][3]) != 0u;
       // where the buffer stands for the batch after this one, and how far memory is written by then
-      const uint32_t shift = stop ? 0u : (b1 + sneg - kH) & ~15u;
+      const uint32_t shift = stop ? 0u : (b1 + sneg - H) & ~15u;
       const uint32_t fl_next = flush_end(sneg, fl, b1);
       if (role == 1) {
         if (nb) {
@@ -1198,7 +1214,7 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
       if (stop) break;
       // ---- slide: the next batch starts right behind kH bytes of history; its literals are already in the buffer
       if (shift) {
-        if (role == 1) stg_slide(stg, shift, kH + 16u + (uni(sh->hdr[cur ^ 1u][1]) - b1) + 16u, lane);
+        if (role == 1) stg_slide(stg, shift, H + 16u + (uni(sh->hdr[cur ^ 1u][1]) - b1) + 16u, lane);
         sneg -= shift;
       }
       PH(8);
@@ -1218,9 +1234,9 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
       op += dn;
       fl = op;
       if (st == kSwitchRun) {
-        sneg = kH + ((op + goff) & 15u) - op;
+        sneg = H + ((op + goff) & 15u) - op;
         vlo = (int32_t)op;
-        if (in_end - ip >= 8u && op > 0) vlo = stg_restore(stg, out, op, sneg, lane);
+        if (in_end - ip >= 8u && (op > 0 || min_pos < 0)) vlo = stg_restore<H>(stg, out, op, sneg, min_pos, lane);
       }
       if (lane < 7)
         sh->ctl[lane] = lane == 0 ? ip : lane == 1 ? op : lane == 2 ? fl : lane == 3 ? sneg : lane == 4 ? (uint32_t)vlo
@@ -1280,8 +1296,9 @@ __device__ __forceinline__ BlockParams load_block_params(const BatchArgs &a, uin
   return p;
 }
 
+template <uint32_t H = kH>
 __device__ __forceinline__ BlockState block_start(const uint8_t *out) {
-  return BlockState{0, 0, 0, kH + (uint32_t)((uintptr_t)out & 15u), 0};
+  return BlockState{0, 0, 0, H + (uint32_t)((uintptr_t)out & 15u), 0};
 }
 
 // Two wavefronts per workgroup, a block each (a wavefront's buffers are what the hardware packs: sixteen wavefronts
@@ -1471,12 +1488,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// One workgroup has the CU's LDS to itself here, so the buffer keeps 32 KiB of history instead of 4: a linked block
+// made of short matches into the block in front of it (what priming the table with the whole history makes of text)
+// finds nearly all of its sources in LDS; only distances beyond 32 KiB are fetched from memory.
+constexpr uint32_t kHChain = 32768, kStgChain = kHChain + 16 + 2 * kBatchOut + 16;
+
 // Linked ("dependent") blocks: block b may reference the 64 KiB that precede it in the
 // frame output, topped up from the dictionary while the output is shorter than that
 // (_decodeDependentBlock, lib/src/frame/lz4_frame_decoder.dart:326-382).  The chain is
 // serial, so one workgroup walks the blocks in order over one contiguous output.
 __global__ __launch_bounds__(128) void decode_chain_kernel(ChainArgs c) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgPairAlloc];
+  __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgChain + 80];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];
   __shared__ __attribute__((aligned(16))) PairShared s_sh;
@@ -1503,9 +1525,10 @@ __global__ __launch_bounds__(128) void decode_chain_kernel(ChainArgs c) {
     } else {
       uint32_t back = start < 65536u ? (uint32_t)start : 65536u;
       if (back < 65536u && c.dict_len) back += c.dict_len < 65536u - back ? c.dict_len : 65536u - back;
-      st = decode_block_pair<false, true, kBatchOut, kStgPair>(payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len,
-                                                               stg, cw, tl, sh, role, lane, produced,
-                                                               block_start(c.dst + start), ParseCtx{0, 0, false, false, 0});
+      st = decode_block_pair<false, true, kBatchOut, kStgChain, kHChain, true>(
+          payload, len, c.dst, start, c.block_max, back, c.dict, c.dict_len, stg, cw, tl, sh, role, lane, produced,
+          block_start<kHChain>(c.dst + start), ParseCtx{0, 0, false, false, 0},
+          start < kHChain ? (uint32_t)start : kHChain);
     }
     if (role == 1 && lane == 0) {
       c.out_len[b] = produced;
