@@ -114,19 +114,30 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 
 // The same for copies of 16 KiB and more (a literal-only block, a stored block): 12 KiB in flight per round trip.
 // A function of its own, not inlined: its twelve 16-byte registers per lane would otherwise count against every
-// kernel that copies anything.
+// kernel that copies anything.  (What is left behind the last 12 KiB goes through wave_copy: taking it in one
+// predicated round trip here as well measured slower, bench decode launch 0.462 -> 0.473 ms.)
 __device__ __attribute__((noinline)) void wave_copy_long(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
+  // Both ranges are device memory: global pointers, so that the loop is global_load / global_store (through the
+  // generic pointers of a function that is not inlined it would be flat instructions, which count against the LDS
+  // counter as well and go through the aperture check).
+  typedef __attribute__((address_space(1))) uint8_t g_u8;
+  typedef u32x4 u32x4_any __attribute__((aligned(1)));  // the source may start at any byte
+  typedef __attribute__((address_space(1))) u32x4_any g_v4any;
+  typedef __attribute__((address_space(1))) u32x4 g_v4;
   const uint32_t head = (uint32_t)(-(uintptr_t)dst) & 15u;
   if (lane < head) dst[lane] = src[lane];
   const uint8_t *s = src + head;
   uint8_t *d = dst + head;
+  const g_u8 *gs = (const g_u8 *)s;
+  g_u8 *gd = (g_u8 *)d;
   uint32_t off = 0;
   for (; off + 12288 <= n - head; off += 12288) {
-    U128U v[12];
+    // streamed once: nontemporal on both sides (scripts/micro/copy_tp.hip: 5.3 against 5.1 TB/s chip-wide)
+    u32x4 v[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = ld128(s + off + 16 * lane + 1024 * k);
+    for (int k = 0; k < 12; k++) v[k] = __builtin_nontemporal_load((const g_v4any *)(gs + off + 16 * lane + 1024 * k));
 #pragma unroll
-    for (int k = 0; k < 12; k++) st128(d + off + 16 * lane + 1024 * k, v[k]);
+    for (int k = 0; k < 12; k++) __builtin_nontemporal_store(v[k], (g_v4 *)(gd + off + 16 * lane + 1024 * k));
   }
   wave_copy(d + off, s + off, n - head - off, lane);
 }
