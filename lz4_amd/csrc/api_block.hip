@@ -213,10 +213,10 @@ static int32_t run_decompress_with(lz4mi_ctx *c, const BatchArgs &a_in, bool str
   }
   uint32_t *counter = counters + kCounterDecode;
   uint32_t *order_cnt = counters + kCounterOrder;
-  // one fill for the decode word and the order words (the encoders' words in between are zeroed by
-  // their own launches before use; everything runs on the context's one stream)
+  // the launch zeroes what it uses: the decode word alone, or in one fill the decode word and the order words
+  // behind it (the encoders' words in between are zeroed by their own launches before use; everything runs on
+  // the context's one stream)
   static_assert(kCounterDecode == 0 && kCounterOrder + 2 <= kNumCounters, "counter layout");
-  LZ4MI_HIP(c, hipMemsetAsync(counters, 0, (kCounterOrder + 2) * sizeof(uint32_t), c->stream));
   launch_decode(a, strict, counter, order_cnt, order, (uint32_t)c->cu_count, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;

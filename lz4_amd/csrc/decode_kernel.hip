@@ -1614,6 +1614,101 @@ __global__ __launch_bounds__(256) void decode_order_place_kernel(uint32_t nblock
   order[pos] = b;
 }
 
+// The order of a launch that ends with its slowest block (up to kOrderSmallMax blocks), in one launch of one
+// workgroup.  Three kinds by what a block will cost: 0 heavy as above; 1 nearly incompressible but not
+// literal-only (compressed to less than one literal run of the output size takes: a text-like block with a few hundred sequences between long
+// literal runs takes 100-300 us on its wavefront, ten times a literal-only block, and as one of the last out
+// of the queue it used to end the launch 50 us behind the last heavy block); 2 streamed (literal-only,
+// run-like, stored).  Kinds in that order, index order within a kind.  The workgroup counts blocks per kind
+// and group of 64 in LDS, scans the counts, places every block and zeroes the queue head on the way.
+constexpr uint32_t kOrderSmallMax = 65536;
+__global__ __launch_bounds__(1024) void decode_order_small_kernel(BatchArgs a, uint32_t *counter, uint32_t *order) {
+  __shared__ uint32_t s_cnt[2][kOrderSmallMax / kWave];  // per kind 0/1: blocks per group, then blocks in front of the group
+  __shared__ uint32_t s_wsum[2][16];
+  const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const uint32_t nb = a.nblocks, ngroups = (nb + kWave - 1) / kWave;
+  if (tid == 0) *counter = 0;
+  // group g = wave + 16 r belongs to this wavefront; bits 2r, 2r+1 of kinds[r / 16]: kind of this lane's block
+  // of that group.  Eight groups per step with their size words in flight together (a single workgroup has
+  // nothing else to hide the round trips with).
+  uint32_t kinds[4] = {0, 0, 0, 0};
+  const uint32_t *sl = a.src_len, *dc = a.dst_cap, *stl = a.stored_len;
+#pragma unroll
+  for (uint32_t r0 = 0; r0 < 64; r0 += 8) {
+    if (r0 * 16 >= ngroups) break;
+    uint32_t bb[8], c[8], n[8], st[8];
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) {
+      const uint32_t b = (wave + 16 * (r0 + u)) * kWave + lane;
+      bb[u] = b < nb ? b : nb - 1;
+    }
+    if (sl) {
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) c[u] = sl[bb[u]];
+    } else {
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) c[u] = block_src_len(a, bb[u]);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) n[u] = a.dst_cap_uniform;
+    if (dc) {
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) n[u] = dc[bb[u]];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) st[u] = 0;
+    if (stl) {
+#pragma unroll
+      for (uint32_t u = 0; u < 8; u++) st[u] = stl[bb[u]];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 8; u++) {
+      const uint32_t g = wave + 16 * (r0 + u);
+      const bool valid = g * kWave + lane < nb;
+      const uint64_t cc = c[u], nn = n[u];
+      uint32_t kind = 2;
+      const uint64_t lit_only = nn + 1 + (nn >= 15 ? (nn - 15) / 255 + 1 : 0);  // token, length bytes, the literals
+      if (st[u] == 0 && cc * 32 > nn) kind = cc * 16 < nn * 15 ? 0u : (cc < lit_only ? 1u : 2u);
+      const uint64_t m0 = ballot(valid && kind == 0), m1 = ballot(valid && kind == 1);
+      if (lane == 0 && g < ngroups) {
+        s_cnt[0][g] = (uint32_t)__builtin_popcountll(m0);
+        s_cnt[1][g] = (uint32_t)__builtin_popcountll(m1);
+      }
+      kinds[(r0 + u) / 16] |= kind << (2 * ((r0 + u) % 16));
+    }
+  }
+  __syncthreads();
+  uint32_t tot[2];
+#pragma unroll
+  for (uint32_t k = 0; k < 2; k++) {
+    const uint32_t v = tid < ngroups ? s_cnt[k][tid] : 0u;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == kWave - 1) s_wsum[k][wave] = incl;
+    __syncthreads();
+    uint32_t wbase = 0, all = 0;
+    for (uint32_t j = 0; j < 16; j++) {
+      const uint32_t t = s_wsum[k][j];
+      if (j < wave) wbase += t;
+      all += t;
+    }
+    tot[k] = all;
+    s_cnt[k][tid] = wbase + incl - v;  // every thread read its own entry above
+  }
+  __syncthreads();
+  const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (uint32_t q = 0; q < 4; q++) {
+    for (uint32_t r = 16 * q; r < 16 * q + 16 && wave + 16 * r < ngroups; r++) {
+      const uint32_t g = wave + 16 * r, b = g * kWave + lane;
+      const bool valid = b < nb;
+      const uint32_t kind = (kinds[q] >> (2 * (r % 16))) & 3u;
+      const uint32_t b0 = s_cnt[0][g] + (uint32_t)__builtin_popcountll(ballot(valid && kind == 0) & below);  // kind-0 blocks below b
+      const uint32_t b1 = s_cnt[1][g] + (uint32_t)__builtin_popcountll(ballot(valid && kind == 1) & below);
+      if (valid) order[kind == 0 ? b0 : kind == 1 ? tot[0] + b1 : tot[0] + tot[1] + (b - b0 - b1)] = b;
+    }
+  }
+}
+
 constexpr uint32_t kMix = 3;            // streamed blocks per heavy block in the queue of a long launch
 constexpr uint32_t kMixFromRounds = 8;  // a launch is long from this many blocks per resident wavefront
 
@@ -1661,12 +1756,18 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
     // few blocks per wavefront: the launch ends with its slowest block, heavy blocks go first
     uint32_t mix = a.nblocks >= kMixFromRounds * grid * per_wg ? kMix : 0u;
     if (mix_env >= 0) mix = (uint32_t)mix_env;
-    uint32_t *tag = order + a.nblocks;
-    const dim3 g((a.nblocks + 255) / 256), blk(256);
-    hipLaunchKernelGGL(decode_order_count_kernel, g, blk, 0, s, a, order_cnt, tag);
-    hipLaunchKernelGGL(decode_order_place_kernel, g, blk, 0, s, a.nblocks, mix, order_cnt, tag, order);
+    if (mix == 0 && a.nblocks <= kOrderSmallMax) {
+      hipLaunchKernelGGL(decode_order_small_kernel, dim3(1), dim3(1024), 0, s, a, counter, order);
+    } else {
+      (void)hipMemsetAsync(counter, 0, (size_t)((order_cnt + 2) - counter) * sizeof(uint32_t), s);
+      uint32_t *tag = order + a.nblocks;
+      const dim3 g((a.nblocks + 255) / 256), blk(256);
+      hipLaunchKernelGGL(decode_order_count_kernel, g, blk, 0, s, a, order_cnt, tag);
+      hipLaunchKernelGGL(decode_order_place_kernel, g, blk, 0, s, a.nblocks, mix, order_cnt, tag, order);
+    }
   } else {
     order = nullptr;
+    (void)hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
   }
   dim3 g(grid), blk(128);
   if (pair) {

@@ -71,8 +71,9 @@ struct ChainArgs {
 };
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s);
-// counter: the queue head, zero at launch; order: TWO words per block (queue order, and scratch for
-// building it), or null: index order; order_cnt: two words, zero at launch.  The grid is sized to the wavefronts that stay resident.
+// counter: the queue head; order: TWO words per block (queue order, and scratch for building it), or null:
+// index order; order_cnt: two words behind counter in the same array.  The launch zeroes the words it uses (on s).
+// The grid is sized to the wavefronts that stay resident.
 void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
                    uint32_t cu_count, hipStream_t s);
 // 0: by launch size, 1: one wavefront per block, 2: two wavefronts per block; returns the previous setting

@@ -35,3 +35,12 @@ for name, fn in [(w, getattr(L, 'lz4mi_debug_%s_spans' % w)) for w in which]:
         print(f"    t={t}: running {(int(((s<=t)&(e>t)).sum()))} heavy running {int(((s<=t)&(e>t)&heavy).sum())} not started {int((s>t).sum())}")
     cls = np.arange(NB) % 8
     print("  per class mean/max duration us:", {int(c): (round(float(d[cls == c].mean())), round(float(d[cls == c].max()))) for c in range(8)})
+    if name == 'dec':  # the blocks that end last: index, class, compressed/output size, start, duration
+        hs = sizes.cpu().numpy()
+        late = np.argsort(-e)[:12]
+        print("  ending last:", [(int(i), int(i) % 8, round(float(hs[i]) / 65536, 3), round(float(s[i])), round(float(d[i]))) for i in late])
+        for c in range(8):
+            m = cls == c
+            slow = m & (d > 150)
+            print(f"    class {c}: size ratio {hs[m].min() / 65536:.3f}-{hs[m].max() / 65536:.3f}, blocks over 150 us: {int(slow.sum())}, "
+                  f"their start p50 {np.percentile(s[slow], 50) if slow.any() else 0:.0f} max {s[slow].max() if slow.any() else 0:.0f}")
