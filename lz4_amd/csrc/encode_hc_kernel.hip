@@ -327,9 +327,15 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
   if (n >= 4) {  // :86-90
     hc_build_index<HAS_DICT>(in, x, total - 3, hist, lane);
     PH(0);
+    // Positions searched per step.  Every position's search stands on its own, so any width gives the
+    // reference's parse; what it changes is the work thrown away: all lanes above the first match searched
+    // for nothing, and every one of them cost scattered index reads (a launch of text-like blocks, a match at
+    // nearly every position, is bound by exactly that traffic).  The width follows the data: four times the
+    // distance to the last match, twice as wide after a step without one.
+    uint32_t width = kWave;
     while (i + 4 <= plimit) {  // :116
       const uint32_t p = i + lane;
-      const bool valid = p + 4 <= plimit;  // a prefix of the lanes
+      const bool valid = p + 4 <= plimit && lane < width;  // a prefix of the lanes
       const uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
       uint32_t seq = 0;
       int32_t idx = -1, lo = 0;
@@ -391,8 +397,10 @@ __device__ __forceinline__ int32_t encode_block_hc(const EncIn in, uint8_t *out,
       }
       if (W == kWave) {  // no match in this window (:190 for each position)
         i += nvalid;
+        width = width * 2 < kWave ? width * 2 : kWave;
         continue;
       }
+      width = 4 * (W + 1) < kWave ? 4 * (W + 1) : kWave;
       // ---- match at lane W (:150-187)
       const uint32_t im = i + W;
       const uint32_t blen = rdlane(best_len, W), bref = rdlane(best_ref, W);
@@ -460,8 +468,11 @@ struct HcKArgs {
 };
 typedef const volatile __attribute__((address_space(4))) HcKArgs *HcKArgsPtr;
 
+#ifndef LZ4MI_HC_WPE
+#define LZ4MI_HC_WPE 4
+#endif
 template <bool HAS_DICT, bool LINKED>
-__global__ __launch_bounds__(256) void encode_hc_kernel(BatchArgs, uint32_t, HcScratch, uint32_t *) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LZ4MI_HC_WPE, LZ4MI_HC_WPE))) void encode_hc_kernel(BatchArgs, uint32_t, HcScratch, uint32_t *) {
   __shared__ uint32_t s_hist[4][512];
   HcKArgsPtr ka = (HcKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
@@ -529,7 +540,8 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   if (max_len > 0x7FFFFFF0u) max_len = 0x7FFFFFF0u;
   const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
   const uint64_t budget = 8ull << 30;  // bytes of index scratch
-  uint32_t slots = (uint32_t)round_up(a.nblocks < c->max_slots ? a.nblocks : c->max_slots, 4);
+  const uint32_t max_slots = (uint32_t)c->cu_count * 4u * LZ4MI_HC_WPE;  // the wavefronts that stay resident
+  uint32_t slots = (uint32_t)round_up(a.nblocks < max_slots ? a.nblocks : max_slots, 4);
   while (slots > 4 && (uint64_t)slots * stride * 20 > budget) slots -= 4;
   const size_t tbl = (size_t)slots * kHashEntries * sizeof(uint32_t);
   LZ4MI_HIP(c, c->hc_floor.ensure(tbl));
