@@ -1629,46 +1629,49 @@ __global__ __launch_bounds__(1024) void decode_order_small_kernel(BatchArgs a, u
   const uint32_t nb = a.nblocks, ngroups = (nb + kWave - 1) / kWave;
   if (tid == 0) *counter = 0;
   // group g = wave + 16 r belongs to this wavefront; bits 2r, 2r+1 of kinds[r / 16]: kind of this lane's block
-  // of that group.  Eight groups per step with their size words in flight together (a single workgroup has
+  // of that group.  Sixteen groups per step with their size words in flight together (a single workgroup has
   // nothing else to hide the round trips with).
+  constexpr uint32_t kStep = 16;  // groups per step: 16384 blocks are one round trip
   uint32_t kinds[4] = {0, 0, 0, 0};
   const uint32_t *sl = a.src_len, *dc = a.dst_cap, *stl = a.stored_len;
 #pragma unroll
-  for (uint32_t r0 = 0; r0 < 64; r0 += 8) {
+  for (uint32_t r0 = 0; r0 < 64; r0 += kStep) {
     if (r0 * 16 >= ngroups) break;
-    uint32_t bb[8], c[8], n[8], st[8];
+    uint32_t bb[kStep], c[kStep], n[kStep], st[kStep];
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) {
+    for (uint32_t u = 0; u < kStep; u++) {
       const uint32_t b = (wave + 16 * (r0 + u)) * kWave + lane;
       bb[u] = b < nb ? b : nb - 1;
     }
     if (sl) {
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) c[u] = sl[bb[u]];
+      for (uint32_t u = 0; u < kStep; u++) c[u] = sl[bb[u]];
     } else {
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) c[u] = block_src_len(a, bb[u]);
+      for (uint32_t u = 0; u < kStep; u++) c[u] = block_src_len(a, bb[u]);
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) n[u] = a.dst_cap_uniform;
+    for (uint32_t u = 0; u < kStep; u++) n[u] = a.dst_cap_uniform;
     if (dc) {
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) n[u] = dc[bb[u]];
+      for (uint32_t u = 0; u < kStep; u++) n[u] = dc[bb[u]];
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) st[u] = 0;
+    for (uint32_t u = 0; u < kStep; u++) st[u] = 0;
     if (stl) {
 #pragma unroll
-      for (uint32_t u = 0; u < 8; u++) st[u] = stl[bb[u]];
+      for (uint32_t u = 0; u < kStep; u++) st[u] = stl[bb[u]];
     }
 #pragma unroll
-    for (uint32_t u = 0; u < 8; u++) {
+    for (uint32_t u = 0; u < kStep; u++) {
       const uint32_t g = wave + 16 * (r0 + u);
       const bool valid = g * kWave + lane < nb;
-      const uint64_t cc = c[u], nn = n[u];
+      // 32-bit arithmetic where it can be: one CU runs this for every block of the launch
+      const uint32_t cu = c[u], nu = n[u];
+      const uint64_t cc = cu, nn = nu;
       uint32_t kind = 2;
-      const uint64_t lit_only = nn + 1 + (nn >= 15 ? (nn - 15) / 255 + 1 : 0);  // token, length bytes, the literals
-      if (st[u] == 0 && cc * 32 > nn) kind = cc * 16 < nn * 15 ? 0u : (cc < lit_only ? 1u : 2u);
+      const uint64_t lit_only = nn + 1 + (nu >= 15 ? (nu - 15) / 255u + 1u : 0u);  // token, length bytes, the literals
+      if (st[u] == 0 && cu > (nu >> 5)) kind = (cc << 4) < nn * 15 ? 0u : (cc < lit_only ? 1u : 2u);
       const uint64_t m0 = ballot(valid && kind == 0), m1 = ballot(valid && kind == 1);
       if (lane == 0 && g < ngroups) {
         s_cnt[0][g] = (uint32_t)__builtin_popcountll(m0);

@@ -326,10 +326,12 @@ def test_block_decoder_long_overlapping_matches(codec, oracle, decode_form):
                 assert out[k, :z].tobytes() == ref, (use_dict, strict, k)
 
 
-def test_block_decoder_queue_order_large_ragged_batch(codec, oracle, decode_form):
+@pytest.mark.parametrize("nb", [24000, 70001])
+def test_block_decoder_queue_order_large_ragged_batch(codec, oracle, decode_form, nb):
     """More blocks than resident wavefronts, so the launch goes through the work queue and its
-    long-blocks-first order: blocks of very different sizes and kinds (literal-only, run-like, mixed,
-    damaged) all come back with the oracle's bytes and status at their own index."""
+    order (24000 blocks: heavy blocks first, built by one workgroup; 70001: the mixed order of a long
+    launch, built by the two-step kernels): blocks of very different sizes and kinds (literal-only,
+    run-like, mixed, damaged) all come back with the oracle's bytes and status at their own index."""
     import torch
     rng = np.random.default_rng(77)
     kinds = []
@@ -340,7 +342,6 @@ def test_block_decoder_queue_order_large_ragged_batch(codec, oracle, decode_form
         kinds.append((oracle.block_compress_hc(data, max_search_depth=4), n))
     kinds.append((_sequence(b"ab", 2, 1200) + _last_literals(b"z"), 1203))
     kinds.append((bytes([0x1F, 0x41, 9, 0, 200]), 300))  # distance beyond the output: corrupt
-    nb = 24000
     pick = rng.integers(0, len(kinds), size=nb)
     offs, blob = [], bytearray()
     for k in pick:
