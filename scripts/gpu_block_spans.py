@@ -8,7 +8,7 @@ from lz4_amd.device import DeviceCodec
 from tools.corpus import corpus
 codec = DeviceCodec(0)
 L = N.load()
-NB = 16384
+NB = int(__import__('os').environ.get('NB', '16384'))  # at most 65536 (size of the stamp arrays)
 src = torch.from_numpy(corpus(NB)).cuda()
 for _ in range(2):
     slots, sizes, st = codec.compress_blocks(src, 65536)
