@@ -48,7 +48,11 @@ __device__ __forceinline__ uint32_t in_ld32(const EncIn &in, uint32_t pos) {
   return v;
 }
 
+#ifdef LZ4MI_TIMING_HASH_BITS  // timing-only builds (wrong output): the same work on a smaller table footprint
+__device__ __forceinline__ uint32_t hash16(uint32_t seq) { return ((seq * 2654435761u) >> 16) & ((1u << LZ4MI_TIMING_HASH_BITS) - 1u); }
+#else
 __device__ __forceinline__ uint32_t hash16(uint32_t seq) { return (seq * 2654435761u) >> 16; }
+#endif
 
 __device__ __forceinline__ uint32_t sched_next(uint32_t o, uint32_t sh) {
   return o < 0x40000000u ? o + 1u + (o >> sh) : o;
