@@ -874,11 +874,56 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
 // lane), sixteen pieces per round trip whichever matches they belong to.  (Data with long distances, and every
 // linked block near its start, has most of its matches here: the round trips are what that costs.)
 constexpr uint32_t kFarPieces = 16;
+#ifndef LZ4MI_FAR_SHORT
+#define LZ4MI_FAR_SHORT 1
+#endif
 template <bool HAS_PREFIX, uint32_t D>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
                                          uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
   uint64_t fm = ballot(q.far);
   if (!fm) return;
+  // Short matches (text-like data through a strong encoder: seven bytes per match at distances all over the
+  // block, so most of them are out of the buffer) would each take a piece of 64 lanes below.  They go eight to a
+  // load instead, eight lanes per match, and every such load of the batch is in flight at once: one round trip
+  // where the pieces took four.  The short matches are first packed into the low lanes (lane k: the k-th of
+  // them), then lane l of load r serves match 8 r + l / 8.
+  if (LZ4MI_FAR_SHORT) {
+    const bool fs = q.far && q.ml <= 8u;
+    const uint64_t sm = ballot(fs);
+    const uint32_t ns = (uint32_t)__builtin_popcountll(sm);
+    if (ns >= 4u) {
+      // forward permute: a lane that holds no short match sends to lane 63, which holds a packed entry only
+      // when all 64 lanes are short matches (and then nobody else sends there)
+      const int to = (int)(4u * (fs ? mbcnt64(sm) : 63u));
+      const uint32_t c_sp = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.sp);
+      const uint32_t c_dl = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((q.o_mat + sneg) | (q.ml << 16)));
+      const uint32_t g = lane >> 3, t = lane & 7u;
+      uint32_t v[8];
+#pragma unroll
+      for (uint32_t r = 0; r < 8; r++) {
+        v[r] = 0;
+        if (8u * r < ns) {
+          const int from = (int)(4u * (8u * r + g));
+          const int32_t sp = __builtin_amdgcn_ds_bpermute(from, (int)c_sp);
+          const uint32_t ml = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)c_dl) >> 16;
+          if (8u * r + g < ns) {  // lanes past the end of a match read its last byte again
+            const int64_t ap = (int64_t)op_start + sp + (int64_t)(t < ml ? t : ml - 1u);
+            v[r] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+          }
+        }
+      }
+#pragma unroll
+      for (uint32_t r = 0; r < 8; r++) {
+        if (8u * r < ns) {
+          const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (8u * r + g)), (int)c_dl);
+          stg[8u * r + g < ns && t < (dl >> 16) ? (dl & 0xffffu) + t : D + lane] = (uint8_t)v[r];
+        }
+      }
+      vm_quiesce();
+      fm &= ~sm;
+      if (!fm) return;
+    }
+  }
   int32_t cs = 0;            // the match being cut into pieces: source position, buffer offset, bytes left
   uint32_t cd = 0, cn = 0;
   for (;;) {

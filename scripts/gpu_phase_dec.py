@@ -8,6 +8,7 @@ from tools.corpus import corpus_block
 codec = DeviceCodec(0)
 L = N.load()
 NB = int(__import__('os').environ.get('NB', '1024'))
+HC = __import__('os').environ.get('HC')
 # phase slots of the two wavefronts of a block (parsing wavefront first)
 names = ['0 before fill barrier', '1 wait: fill barrier', '2 copier: out-of-buffer matches', '3 copier: matches', '4 copier: flush',
          '5 parser: chain + lane fields', '6 parser: literals', '7 wait: batch barrier', '8 copier: slide', '9 wait: slide barrier',
@@ -16,7 +17,7 @@ for arg in sys.argv[1:] or ['5']:
     idx = [int(x) for x in arg.split(',')]
     blocks = [corpus_block(i) for i in idx]
     src = torch.from_numpy(np.concatenate([blocks[k % len(blocks)] for k in range(NB)])).cuda()
-    slots, sizes, st = codec.compress_blocks(src, 65536)
+    slots, sizes, st = codec.compress_blocks(src, 65536, **({'hc_depth': int(HC)} if HC else {}))  # HC=<depth>: the HC encoder's output (short sequences)
     codec.decompress_blocks(slots, sizes, 65536); torch.cuda.synchronize()
     buf = (C.c_ulonglong * 32)()
     L.lz4mi_debug_dec_phases(buf, 1)
