@@ -877,18 +877,22 @@ constexpr uint32_t kFarPieces = 16;
 #ifndef LZ4MI_FAR_SHORT
 #define LZ4MI_FAR_SHORT 1
 #endif
+#ifndef LZ4MI_FAR_SLOT
+#define LZ4MI_FAR_SLOT 16
+#endif
 template <bool HAS_PREFIX, uint32_t D>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
                                          uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
   uint64_t fm = ballot(q.far);
   if (!fm) return;
   // Short matches (text-like data through a strong encoder: seven bytes per match at distances all over the
-  // block, so most of them are out of the buffer) would each take a piece of 64 lanes below.  They go eight to a
-  // load instead, eight lanes per match, and every such load of the batch is in flight at once: one round trip
-  // where the pieces took four.  The short matches are first packed into the low lanes (lane k: the k-th of
-  // them), then lane l of load r serves match 8 r + l / 8.
+  // block, so most of them are out of the buffer) would each take a piece of 64 lanes below.  They go four to a
+  // load instead, sixteen lanes per match (eight and thirty-two lanes per match measured slower), eight loads in
+  // flight: 32 matches per round trip where the pieces took two round trips.  The short matches are first
+  // packed into the low lanes (lane k: the k-th of them), then lane l of load r serves match 4 r + l / 16.
   if (LZ4MI_FAR_SHORT) {
-    const bool fs = q.far && q.ml <= 8u;
+    constexpr uint32_t S = LZ4MI_FAR_SLOT, PER = kWave / S;  // lanes per match, matches per load
+    const bool fs = q.far && q.ml <= S;
     const uint64_t sm = ballot(fs);
     const uint32_t ns = (uint32_t)__builtin_popcountll(sm);
     if (ns >= 4u) {
@@ -897,29 +901,31 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
       const int to = (int)(4u * (fs ? mbcnt64(sm) : 63u));
       const uint32_t c_sp = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.sp);
       const uint32_t c_dl = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((q.o_mat + sneg) | (q.ml << 16)));
-      const uint32_t g = lane >> 3, t = lane & 7u;
-      uint32_t v[8];
+      const uint32_t g = lane / S, t = lane % S;
+      for (uint32_t k0 = 0; k0 < ns; k0 += 8u * PER) {  // eight loads in flight
+        uint32_t v[8];
 #pragma unroll
-      for (uint32_t r = 0; r < 8; r++) {
-        v[r] = 0;
-        if (8u * r < ns) {
-          const int from = (int)(4u * (8u * r + g));
-          const int32_t sp = __builtin_amdgcn_ds_bpermute(from, (int)c_sp);
-          const uint32_t ml = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)c_dl) >> 16;
-          if (8u * r + g < ns) {  // lanes past the end of a match read its last byte again
-            const int64_t ap = (int64_t)op_start + sp + (int64_t)(t < ml ? t : ml - 1u);
-            v[r] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+        for (uint32_t r = 0; r < 8; r++) {
+          v[r] = 0;
+          if (k0 + PER * r < ns) {
+            const int from = (int)(4u * (k0 + PER * r + g));
+            const int32_t sp = __builtin_amdgcn_ds_bpermute(from, (int)c_sp);
+            const uint32_t ml = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)c_dl) >> 16;
+            if (k0 + PER * r + g < ns) {  // lanes past the end of a match read its last byte again
+              const int64_t ap = (int64_t)op_start + sp + (int64_t)(t < ml ? t : ml - 1u);
+              v[r] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+            }
           }
         }
-      }
 #pragma unroll
-      for (uint32_t r = 0; r < 8; r++) {
-        if (8u * r < ns) {
-          const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (8u * r + g)), (int)c_dl);
-          stg[8u * r + g < ns && t < (dl >> 16) ? (dl & 0xffffu) + t : D + lane] = (uint8_t)v[r];
+        for (uint32_t r = 0; r < 8; r++) {
+          if (k0 + PER * r < ns) {
+            const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (k0 + PER * r + g)), (int)c_dl);
+            stg[k0 + PER * r + g < ns && t < (dl >> 16) ? (dl & 0xffffu) + t : D + lane] = (uint8_t)v[r];
+          }
         }
+        vm_quiesce();
       }
-      vm_quiesce();
       fm &= ~sm;
       if (!fm) return;
     }
