@@ -970,6 +970,9 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
 // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
 // byte by byte: output byte k is byte k mod dist of the period in front of the match.
 // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
+#ifndef LZ4MI_NEAR_PACK
+#define LZ4MI_NEAR_PACK 1
+#endif
 template <uint32_t D>
 __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_t nb, const SeqLane &q, uint32_t lane) {
   // Every value the copy loop needs sits in a register of its own, ready for one cross-lane read: the loop
@@ -982,8 +985,48 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   const uint32_t m_src = ((uint32_t)q.sp + sneg) & 0xffffu, m_dst = q.o_mat + sneg;
   const uint32_t m_len = q.far ? 0u : q.ml, m_per = ovl ? q.dist : 0xffffu;
   const uint32_t m_mg = ovl ? 65536u / q.dist + 1u : 0u, m_step = ovl ? 64u % q.dist : kWave;
+  // Short matches out of the history: a match of at most sixteen bytes whose source ends in front of the batch's
+  // first output byte reads nothing that this batch writes, so all of them are copied first, packed four to an
+  // LDS operation (sixteen lanes per match, as the out-of-buffer loads are), every read of a round queued before
+  // its writes.  What is left for the loop below keeps its order, and none of it reads a byte that such a match
+  // writes later than the loop expects: a later match's output lies behind an earlier match's source.
+  uint32_t m_todo = m_len;
+  if (LZ4MI_NEAR_PACK) {
+    const bool pk = lane < nb && m_len != 0 && m_len <= 16u && !ovl &&
+                    q.sp + (int32_t)q.ml <= (int32_t)rdlane(q.o_lit, 0);
+    const uint64_t pm = ballot(pk);
+    const uint32_t np = (uint32_t)__builtin_popcountll(pm);
+    if (np >= 4u) {
+      const int to = (int)(4u * (pk ? mbcnt64(pm) : 63u));  // lane k: the k-th of them (lane 63 takes the rest)
+      const uint32_t c_sl = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)(m_src | (m_len << 16)));
+      const uint32_t c_d = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)m_dst);
+      const uint32_t g = lane >> 4, t = lane & 15u;
+      for (uint32_t k0 = 0; k0 < np; k0 += 32u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+          v[r] = 0;
+          if (k0 + 4u * r < np) {
+            const uint32_t k = k0 + 4u * r + g;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * k), (int)c_sl);
+            v[r] = stg[k < np ? (a & 0xffffu) + t : D + lane];
+          }
+        }
+#pragma unroll
+        for (uint32_t r = 0; r < 8; r++) {
+          if (k0 + 4u * r < np) {
+            const uint32_t k = k0 + 4u * r + g;
+            const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * k), (int)c_sl);
+            const uint32_t dd = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * k), (int)c_d);
+            stg[k < np && t < (a >> 16) ? dd + t : D + lane] = (uint8_t)v[r];
+          }
+        }
+      }
+      if (pk) m_todo = 0;
+    }
+  }
   for (uint32_t j = 0; j < nb; j++) {
-    const uint32_t m = rdlane(m_len, j);
+    const uint32_t m = rdlane(m_todo, j);
     if (!m) continue;
     const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
     const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
