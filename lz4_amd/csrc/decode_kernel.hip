@@ -1025,9 +1025,7 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
       if (pk) m_todo = 0;
     }
   }
-  for (uint32_t j = 0; j < nb; j++) {
-    const uint32_t m = rdlane(m_todo, j);
-    if (!m) continue;
+  const auto one = [&](uint32_t j, uint32_t m) __attribute__((always_inline)) {
     const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
     const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
     uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
@@ -1036,6 +1034,20 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
       stg[k0 + lane < m ? md + k0 : D + lane] = (uint8_t)v;
       r += step;
       r = r >= per ? r - per : r;
+    }
+  };
+  // Most of the batch still to copy: count through it.  Few left (the rest was out of the buffer or went packed):
+  // step from one to the next over a bit mask, which costs a little more per match and nothing per skipped one.
+  const uint64_t left0 = ballot(lane < nb && m_todo != 0);
+  if (2u * (uint32_t)__builtin_popcountll(left0) > nb) {
+    for (uint32_t j = 0; j < nb; j++) {
+      const uint32_t m = rdlane(m_todo, j);
+      if (m) one(j, m);
+    }
+  } else {
+    for (uint64_t left = left0; left; left &= left - 1ull) {
+      const uint32_t j = (uint32_t)__builtin_ctzll(left);
+      one(j, rdlane(m_todo, j));
     }
   }
 }
