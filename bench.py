@@ -55,21 +55,33 @@ CPU_NOTE = ("C port of the reference algorithm (bit-identical output): an upper 
             "on the same cores; the Dart SDK is absent on this host, so benchmark/lz4_benchmark.dart itself cannot run")
 
 
-def _pool(fn, n_items, threads):
+def _spans(n_items, threads):
     step = (n_items + threads * 8 - 1) // (threads * 8)
-    spans = [(lo, min(n_items, lo + step)) for lo in range(0, n_items, step)]
-    t0 = time.perf_counter()
-    if threads == 1:
-        for lo, hi in spans:
-            fn(lo, hi)
-    else:
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda s: fn(*s), spans))
-    return time.perf_counter() - t0
+    return [(lo, min(n_items, lo + step)) for lo in range(0, n_items, step)]
 
 
-def cpu_baseline(data: np.ndarray, threads: int, hc_depth: int | None = None):
-    """The scalar C oracle (bit-identical output) on the host cores: same blocks, same round trip."""
+def reference_throughput(fn, bytes_processed, warmup_iters=8, target_ms=500.0):
+    """The reference harness's timing rule (benchmark/lz4_benchmark.dart:154-183): `warmup_iters` untimed calls,
+    then batches of 1, 2, 4, ... calls until one timed batch lasts `target_ms`; MiB/s of that batch."""
+    for _ in range(warmup_iters):
+        fn()
+    iters = 1
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        dt = time.perf_counter() - t0
+        if dt * 1e3 >= target_ms:
+            return bytes_processed * iters / (1024.0 * 1024.0) / dt, iters
+        iters *= 2
+
+
+def cpu_baseline(data: np.ndarray, threads: int, hc_depth: int | None = None, dictionary: bytes | None = None,
+                 label: str = "fast"):
+    """The scalar C oracle (bit-identical output) on the host cores: same blocks, same round trip, timed by the
+    reference harness's rule, once on `threads` threads (one block per task) and once on one thread (a prefix of
+    the blocks, so that the whole leg stays within seconds).  Prints the reference's `[label] compress: X MiB/s`
+    lines (benchmark/lz4_benchmark.dart:92-93) to stderr."""
     from oracle import lz4ref
     L = lz4ref.lib()
     import ctypes as C
@@ -78,45 +90,79 @@ def cpu_baseline(data: np.ndarray, threads: int, hc_depth: int | None = None):
     comp = np.empty((nb, bound), dtype=np.uint8)
     sizes = np.zeros(nb, dtype=np.int64)
     conf = np.zeros(nb, dtype=np.int64)
+    dlen = len(dictionary) if dictionary else 0
+    dbuf = np.frombuffer(dictionary, dtype=np.uint8).copy() if dlen else None
+    # decode goes through the lenient decoder behind a dictionary prefix when there is one (what the frame decoder
+    # does per block, lib/src/frame/lz4_frame_decoder.dart:273-290): one prefix + output area per worker span
     out = np.empty(nb * BLOCK, dtype=np.uint8)
     src_p, comp_p, out_p = data.ctypes.data, comp.ctypes.data, out.ctypes.data
 
-    def enc(lo, hi):
-        n = C.c_size_t(0)
-        for b in range(lo, hi):
-            if hc_depth is None:
-                L.lz4ref_block_compress_fast(C.c_char_p(src_p + b * BLOCK), BLOCK, None, 0, 1,
-                                             C.c_void_p(comp_p + b * bound), bound, C.byref(n))
-            else:
-                L.lz4ref_block_compress_hc(C.c_char_p(src_p + b * BLOCK), BLOCK, None, 0, hc_depth,
-                                           C.c_void_p(comp_p + b * bound), bound, C.byref(n))
-            sizes[b] = n.value
+    level, param = (0, 1) if hc_depth is None else (1, hc_depth)
+    sizes_p = sizes.ctypes.data
+    dict_addr = dbuf.ctypes.data if dlen else None
+
+    def enc(lo, hi):  # one C call per span of blocks: the GIL is released for all of it
+        st = L.lz4ref_blocks_compress(src_p + lo * BLOCK, hi - lo, BLOCK, dict_addr, dlen, level, param,
+                                      comp_p + lo * bound, bound, sizes_p + 8 * lo)
+        assert st == 0, st
 
     def dec(lo, hi):
-        for b in range(lo, hi):
-            L.lz4ref_block_decompress(C.c_char_p(comp_p + b * bound), int(sizes[b]),
-                                      C.c_void_p(out_p + b * BLOCK), BLOCK)
+        tmp = None
+        if dlen:
+            tmp = np.empty(dlen + BLOCK, dtype=np.uint8)
+            tmp[:dlen] = dbuf
+        st = L.lz4ref_blocks_decompress(comp_p + lo * bound, bound, sizes_p + 8 * lo, hi - lo, BLOCK,
+                                        tmp.ctypes.data if dlen else None, dlen, out_p + lo * BLOCK)
+        assert st == 0, st
 
-    t_enc = _pool(enc, nb, threads)
-    t_dec = _pool(dec, nb, threads)
+    def run(fn, n_items, nthreads, ex):
+        spans = _spans(n_items, nthreads)
+        if ex is None:
+            return lambda: [fn(lo, hi) for lo, hi in spans]
+        return lambda: list(ex.map(lambda s: fn(*s), spans))
+
+    one = min(nb, 2048 if hc_depth is None else 64)  # the one-thread leg works on a prefix
+    mib = {}
+    iters = {}
+    with ThreadPoolExecutor(threads) as ex:
+        run(enc, nb, threads, ex)()  # sizes[] of every block before anything is timed
+        for name, fn in (("compress", enc), ("decompress", dec)):
+            warm, target = (8, 500.0) if hc_depth is None else (1, 500.0)  # an HC pass takes seconds by itself
+            mib[name], iters[name] = reference_throughput(run(fn, nb, threads, ex), nb * BLOCK, warm, target)
     assert np.array_equal(out, data)
+    for name, fn in (("compress", enc), ("decompress", dec)):
+        warm = 8 if hc_depth is None else 1
+        mib[name + "_1"], iters[name + "_1"] = reference_throughput(run(fn, one, 1, None), one * BLOCK, warm, 500.0)
     for b in range(nb):  # not timed: blocks that break the LZ4 end-of-block rules
         conf[b] = 0 if L.lz4ref_block_conformant(C.c_char_p(comp_p + b * bound), int(sizes[b])) else 1
-    one = min(nb, 2048 if hc_depth is None else 64)  # single-thread figure on a prefix
-    t1 = 0.0
-    for fn in (enc, dec):
-        t0 = time.perf_counter()
-        fn(0, one)
-        t1 += time.perf_counter() - t0
-    gb = data.size / 1e9
+    total_c = int(sizes.sum())
+    print(f"--- synthetic mixed-entropy {data.size >> 20}MiB, 64KiB blocks: C port of the reference on host cores ---",
+          file=sys.stderr)
+    print(f"input: {data.size} bytes", file=sys.stderr)
+    print(f"[{label}] compressed: {total_c} bytes (ratio: {total_c / data.size:.3f})", file=sys.stderr)
+    print(f"[{label}] compress: {mib['compress']:.1f} MiB/s", file=sys.stderr)
+    print(f"[{label}] decompress: {mib['decompress']:.1f} MiB/s", file=sys.stderr)
+    print(f"[{label}-1thread] compress: {mib['compress_1']:.1f} MiB/s", file=sys.stderr)
+    print(f"[{label}-1thread] decompress: {mib['decompress_1']:.1f} MiB/s", file=sys.stderr)
+    to_gb = 1024.0 * 1024.0 / 1e9
+    c, d, c1, d1 = (mib[k] * to_gb for k in ("compress", "decompress", "compress_1", "decompress_1"))
     return {
-        "value": gb / (t_enc + t_dec), "unit": "GB/s", "cores": threads, "kind": "port",
-        "sample": f"{data.size >> 20} MiB of the corpus, {nb} blocks, compress+decompress round trip, "
-                  f"{threads} threads (one block per task)",
+        "value": 1.0 / (1.0 / c + 1.0 / d), "unit": "GB/s", "cores": threads, "kind": "port",
+        "sample": f"{data.size >> 20} MiB of the corpus, {nb} blocks, compress and decompress each timed by the "
+                  f"reference harness's rule (8 warm-up passes, then 1, 2, 4, ... passes until a timed batch lasts "
+                  f"500 ms; benchmark/lz4_benchmark.dart:154-183), {threads} threads (one block per task); value = "
+                  f"round-trip rate 1 / (1/compress + 1/decompress)"
+                  + (f"; dictionary of {dlen} bytes on both sides" if dlen else ""),
         "note": CPU_NOTE,
-        "compress_GBps": gb / t_enc, "decompress_GBps": gb / t_dec,
-        "value_1thread": one * BLOCK / 1e9 / t1,
-        "compressed_bytes": int(sizes.sum()),
+        "host_cpu_count": os.cpu_count(),
+        "compress_GBps": c, "decompress_GBps": d,
+        "compress_MiBps": mib["compress"], "decompress_MiBps": mib["decompress"],
+        "timed_passes": {k: iters[k] for k in ("compress", "decompress")},
+        "value_1thread": 1.0 / (1.0 / c1 + 1.0 / d1),
+        "compress_GBps_1thread": c1, "decompress_GBps_1thread": d1,
+        "sample_1thread": f"first {one} blocks, same rule",
+        "compressed_bytes": total_c,
+        "blocks": nb,
         "nonconformant_blocks": int(conf.sum()),
     }
 
@@ -136,12 +182,17 @@ def load_corpus(dev, first_block, nblocks):
     return src, host0
 
 
-def traffic_of(kernel):
+def traffic_of(kernel, blocks_per_launch, phase):
+    """HBM bytes per launch from the PMC passes, or None when they profiled another launch shape than this run's
+    (another number of blocks per launch, or the sharded step's window kernels)."""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tpath)).get(kernel, {}).get("hbm_bytes_per_launch")
+        rec = json.load(open(tpath)).get(kernel, {})
     except Exception:
         return None
+    if phase != kernel or rec.get("blocks_per_launch", 16384) != blocks_per_launch:
+        return None
+    return rec.get("hbm_bytes_per_launch")
 
 
 def main():
@@ -377,7 +428,7 @@ def main():
             "phase_ms": ms,
             "roofline": {
                 "kernel": dom_kernel, "bound": "hbm", "achieved": roof[dom]["achieved"], "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": roof[dom]["frac"], "traffic": traffic_of(dom_kernel),
+                "unit": "GB/s", "frac": roof[dom]["frac"], "traffic": traffic_of(dom_kernel, nb, dom),
                 "traffic_source": "profiles/traffic.json (PMC passes of scripts/collect_profiles.sh on this workload)",
                 "algorithmic_bytes_per_launch": n_bytes + total_c, "avg_launch_ms": roof[dom]["avg_launch_ms"],
             },
@@ -388,7 +439,10 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             cb = cpu_baseline(data0, threads)
             result["cpu_baseline"] = cb
-            result["config"]["ratio_parity"] = (cb["compressed_bytes"] == total_c)
+            # the oracle works on the first cb["blocks"] blocks (all of them up to 1 GiB per launch)
+            gpu_c = int(keep["sizes"][: cb["blocks"]].to(torch.int64).sum())
+            result["config"]["ratio_parity"] = (cb["compressed_bytes"] == gpu_c)
+            result["config"]["ratio_parity_blocks"] = cb["blocks"]
             result["config"]["nonconformant_blocks_oracle"] = cb["nonconformant_blocks"]
         else:
             result["cpu_baseline"] = None

@@ -80,6 +80,10 @@ typedef struct lz4mi_ctx lz4mi_ctx;
 int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **out);
 void lz4mi_ctx_destroy(lz4mi_ctx *ctx);
 int32_t lz4mi_ctx_synchronize(lz4mi_ctx *ctx);
+/* Device memory the context holds at the moment, in bytes: every scratch buffer it has allocated
+ * (hash tables, staging, per-block bookkeeping, search index).  No counterpart in the reference;
+ * lets a caller size its own allocations and watch that a call allocated nothing. */
+uint64_t lz4mi_ctx_device_bytes(lz4mi_ctx *ctx);
 /* ctx == NULL: reason of the last failed lz4mi_ctx_create */
 const char *lz4mi_last_backend_error(lz4mi_ctx *ctx);
 /* nonzero when built with the HIP kernels for gfx950 (always, in this build) */
@@ -100,7 +104,10 @@ int32_t lz4mi_block_compress_fast(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
                                   uint8_t *dst, size_t cap, size_t *out_len);
 
 /* lz4Compress(level: hc) -> lz4HcBlockCompress  lib/src/hc/lz4_hc_block_encoder.dart:38-197;
- * max_search_depth < 1 -> LZ4MI_RANGE (lib/src/hc/lz4_hc_options.dart:13-15). */
+ * max_search_depth < 1 -> LZ4MI_RANGE (lib/src/hc/lz4_hc_options.dart:13-15).
+ * The search index takes 20 bytes of device scratch per input byte (dictionary included): a block
+ * whose index does not fit the device's free memory (with 288 GB, blocks of several GiB would not)
+ * returns LZ4MI_UNSUPPORTED_HERE with the sizes in lz4mi_last_backend_error(ctx). */
 int32_t lz4mi_block_compress_hc(lz4mi_ctx *ctx, const uint8_t *src, size_t n,
                                 const uint8_t *dict, size_t dict_len, int64_t max_search_depth,
                                 uint8_t *dst, size_t cap, size_t *out_len);
@@ -187,8 +194,12 @@ int32_t lz4mi_decompress_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t str
  * ends) instead of context buffers, so the call performs no hipMalloc/hipFree.
  * At most LZ4MI_STATIC_MAX_BLOCKS blocks per call: more -> LZ4MI_UNSUPPORTED_HERE with the
  * reason in lz4mi_last_backend_error(ctx), nothing launched.  All contexts on one GPU share
- * that array: calls that overlap in time on the same GPU (two contexts, two streams) race on
- * it; calls on one context's stream are ordered and safe. */
+ * that array.  Calls on one stream are ordered by the stream; a call that arrives on another
+ * stream than the array's last user makes its stream wait for that user's launch first (an
+ * event recorded behind every launch, hipStreamWaitEvent, no allocation), so calls from
+ * several contexts or threads take turns instead of racing.  What stays the caller's: a
+ * stream under graph capture must be the only user of this entry point on its GPU while the
+ * graph is captured and replayed (a replay records no event). */
 #define LZ4MI_STATIC_MAX_BLOCKS (1u << 20)
 int32_t lz4mi_decompress_batch_static(lz4mi_ctx *ctx, const lz4mi_batch *b, int32_t strict);
 
@@ -197,8 +208,12 @@ int32_t lz4mi_decompress_batch_static(lz4mi_ctx *ctx, const lz4mi_batch *b, int3
  * slots empty give every block a workgroup of two wavefronts (one finds the sequences and places the
  * literals of the next batch while the other copies the matches of the current one: a block is done in
  * 0.6 of the time), larger launches give every block one wavefront (twice as many blocks in flight).
- * 1: always one wavefront per block.  2: always two.  Process-wide; returns the previous setting, or
- * -1 for a value out of range.  The environment variable LZ4MI_DEC_FORM=single|pair sets the start value. */
+ * 1: always one wavefront per block.  2: always two.
+ * lz4mi_ctx_set_decode_form sets it for one context (form -1: follow the process default again) and returns
+ * the context's previous setting (-2 for a bad argument).  lz4mi_set_decode_form sets the process default
+ * that contexts without a setting of their own follow; it returns the previous default, or -1 for a value
+ * out of range.  The environment variable LZ4MI_DEC_FORM=single|pair sets the start value of the default. */
+int32_t lz4mi_ctx_set_decode_form(lz4mi_ctx *ctx, int32_t form);
 int32_t lz4mi_set_decode_form(int32_t form);
 
 /* xxh32 of each block's source bytes (seed 0): block checksums

@@ -69,10 +69,10 @@ class FrameInfo(C.Structure):
 # every symbol include/lz4mi.h declares
 EXPORTS = [
     "lz4mi_status_type", "lz4mi_status_message", "lz4mi_ctx_create", "lz4mi_ctx_destroy",
-    "lz4mi_ctx_synchronize", "lz4mi_last_backend_error", "lz4mi_version", "lz4mi_compress_bound",
+    "lz4mi_ctx_synchronize", "lz4mi_ctx_device_bytes", "lz4mi_last_backend_error", "lz4mi_version", "lz4mi_compress_bound",
     "lz4mi_block_compress_fast", "lz4mi_block_compress_hc", "lz4mi_block_decompress",
     "lz4mi_block_decompress_into", "lz4mi_xxh32", "lz4mi_compress_fast_batch", "lz4mi_compress_hc_batch",
-    "lz4mi_decompress_batch", "lz4mi_decompress_batch_static", "lz4mi_set_decode_form", "lz4mi_xxh32_batch", "lz4mi_xxh32_device", "lz4mi_frame_options_default",
+    "lz4mi_decompress_batch", "lz4mi_decompress_batch_static", "lz4mi_set_decode_form", "lz4mi_ctx_set_decode_form", "lz4mi_xxh32_batch", "lz4mi_xxh32_device", "lz4mi_frame_options_default",
     "lz4mi_frame_bound", "lz4mi_frame_encode", "lz4mi_frame_encode_device", "lz4mi_frame_shard_compress",
     "lz4mi_frame_shard_write", "lz4mi_frame_header", "lz4mi_frame_decode_next", "lz4mi_frame_decode_bound",
     "lz4mi_xxh32_state_init", "lz4mi_xxh32_state_update", "lz4mi_xxh32_state_digest",
@@ -114,6 +114,8 @@ def load():
         L.lz4mi_ctx_destroy.argtypes = [vp]
         L.lz4mi_ctx_destroy.restype = None
         L.lz4mi_ctx_synchronize.argtypes = [vp]
+        L.lz4mi_ctx_device_bytes.restype = u64
+        L.lz4mi_ctx_device_bytes.argtypes = [vp]
         L.lz4mi_last_backend_error.restype = C.c_char_p
         L.lz4mi_last_backend_error.argtypes = [vp]
         L.lz4mi_compress_bound.restype = sz
@@ -128,6 +130,7 @@ def load():
         L.lz4mi_decompress_batch.argtypes = [vp, C.POINTER(Batch), i32]
         L.lz4mi_decompress_batch_static.argtypes = [vp, C.POINTER(Batch), i32]
         L.lz4mi_set_decode_form.argtypes = [i32]
+        L.lz4mi_ctx_set_decode_form.argtypes = [C.c_void_p, i32]
         L.lz4mi_xxh32_batch.argtypes = [vp, C.POINTER(Batch), vp]
         L.lz4mi_xxh32_device.argtypes = [vp, vp, u64, u32, vp]
         L.lz4mi_frame_options_default.argtypes = [C.POINTER(FrameOptions)]

@@ -2,6 +2,8 @@
 // device-resident batches) and xxHash32.  See include/lz4mi.h for the contract.
 #include "api_common.h"
 
+#include <mutex>
+
 using namespace lz4mi;
 
 // ------------------------------------------------------------------ status
@@ -75,6 +77,21 @@ constexpr uint32_t kStaticMaxBlocks = LZ4MI_STATIC_MAX_BLOCKS;
 constexpr uint32_t kStaticHead = 64;  // words in front of the order list (queue heads)
 static __device__ __align__(256) uint32_t scratch[kStaticHead + 2 * kStaticMaxBlocks];  // two order words per block
 
+// Every context on a GPU shares that GPU's scratch array, so launches that use it are put in order here: the
+// last one's stream and an event recorded behind it are kept per device, and a call that arrives on another
+// stream first makes its stream wait for that event (no allocation: the event is created with the device's
+// first context).  Calls from several threads take the device's lock around wait + launch + record.
+namespace {
+struct StaticGuard {
+  std::mutex mu;
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+};
+constexpr int kMaxDevices = 64;
+StaticGuard g_static_guard[kMaxDevices];
+}  // namespace
+
 static int32_t create_fail(lz4mi_ctx *c, hipError_t e, const char *what) {
   g_create_error = std::string(what) + ": " + hipGetErrorString(e);
   if (c) lz4mi_ctx_destroy(c);
@@ -111,6 +128,12 @@ extern "C" int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **ou
   if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess || !sp)
     return create_fail(c, e, "hipGetSymbolAddress(scratch)");
   c->static_scratch = (uint32_t *)sp;
+  if (device < kMaxDevices) {
+    StaticGuard &g = g_static_guard[device];
+    std::lock_guard<std::mutex> lock(g.mu);
+    if (!g.done && (e = hipEventCreateWithFlags(&g.done, hipEventDisableTiming)) != hipSuccess)
+      return create_fail(c, e, "hipEventCreateWithFlags");
+  }
   uint32_t wpc = 16;  // resident encoder wavefronts per CU (one 256 KiB table each)
   if (const char *v = getenv("LZ4MI_ENC_WAVES_PER_CU")) {
     int n = atoi(v);
@@ -121,19 +144,37 @@ extern "C" int32_t lz4mi_ctx_create(int32_t device, void *stream, lz4mi_ctx **ou
   return LZ4MI_OK;
 }
 
+static std::vector<DevBuf *> ctx_buffers(lz4mi_ctx *c);
+
 extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf *bufs[] = {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
-                    &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
-                    &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
-                    &c->hc_chain, &c->hc_floor, &c->order};
-  for (DevBuf *b : bufs) b->release();
+  for (DevBuf *b : ctx_buffers(c)) b->release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->side_stream) {
+    (void)hipStreamSynchronize(c->side_stream);
+    (void)hipStreamDestroy(c->side_stream);
+  }
+  if (c->side_fork) (void)hipEventDestroy(c->side_fork);
+  if (c->side_join) (void)hipEventDestroy(c->side_join);
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
+}
+
+static std::vector<DevBuf *> ctx_buffers(lz4mi_ctx *c) {
+  return {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
+          &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
+          &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
+          &c->hc_chain, &c->hc_floor, &c->order};
+}
+
+extern "C" uint64_t lz4mi_ctx_device_bytes(lz4mi_ctx *c) {
+  if (!c) return 0;
+  uint64_t n = c->d_counters ? kNumCounters * sizeof(uint32_t) : 0;
+  for (DevBuf *b : ctx_buffers(c)) n += b->cap;
+  return n;
 }
 
 extern "C" int32_t lz4mi_ctx_synchronize(lz4mi_ctx *c) {
@@ -144,6 +185,13 @@ extern "C" int32_t lz4mi_ctx_synchronize(lz4mi_ctx *c) {
 extern "C" const char *lz4mi_last_backend_error(lz4mi_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 namespace lz4mi {
+
+int32_t side_stream_ready(lz4mi_ctx *c) {
+  if (!c->side_stream) LZ4MI_HIP(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  if (!c->side_fork) LZ4MI_HIP(c, hipEventCreateWithFlags(&c->side_fork, hipEventDisableTiming));
+  if (!c->side_join) LZ4MI_HIP(c, hipEventCreateWithFlags(&c->side_join, hipEventDisableTiming));
+  return LZ4MI_OK;
+}
 
 int32_t pin_reserve(lz4mi_ctx *c, size_t n) {
   if (n <= c->h_pin_cap) return LZ4MI_OK;
@@ -217,8 +265,7 @@ static int32_t run_decompress_with(lz4mi_ctx *c, const BatchArgs &a_in, bool str
   // behind it (the encoders' words in between are zeroed by their own launches before use; everything runs on
   // the context's one stream)
   static_assert(kCounterDecode == 0 && kCounterOrder + 2 <= kNumCounters, "counter layout");
-  launch_decode(a, strict, counter, order_cnt, order, (uint32_t)c->cu_count, c->stream);
-  LZ4MI_HIP(c, hipGetLastError());
+  LZ4MI_HIP(c, launch_decode(a, strict, counter, order_cnt, order, (uint32_t)c->cu_count, c->decode_form, c->stream));
   return LZ4MI_OK;
 }
 
@@ -236,7 +283,23 @@ int32_t run_decompress_static(lz4mi_ctx *c, const BatchArgs &a, bool strict) {
              std::to_string(kStaticMaxBlocks);
     return LZ4MI_UNSUPPORTED_HERE;
   }
-  return run_decompress_with(c, a, strict, c->static_scratch, c->static_scratch + kStaticHead);
+  if (a.nblocks == 0) return LZ4MI_OK;
+  if (c->device >= kMaxDevices) {
+    c->err = "lz4mi_decompress_batch_static: device ordinal beyond the per-device guard table";
+    return LZ4MI_UNSUPPORTED_HERE;
+  }
+  StaticGuard &g = g_static_guard[c->device];
+  std::lock_guard<std::mutex> lock(g.mu);
+  // the scratch array's last user ran on another stream: this launch waits for it instead of racing with it
+  if (g.used && g.last != c->stream) LZ4MI_HIP(c, hipStreamWaitEvent(c->stream, g.done, 0));
+  const int32_t st = run_decompress_with(c, a, strict, c->static_scratch, c->static_scratch + kStaticHead);
+  // Whatever was enqueued (also by a launch sequence that failed half-way) is what the next user has to wait for.
+  const hipError_t e = hipEventRecord(g.done, c->stream);
+  g.last = c->stream;
+  g.used = true;
+  if (st) return st;
+  LZ4MI_HIP(c, e);
+  return LZ4MI_OK;
 }
 
 static void to_args(const lz4mi_batch *b, BatchArgs &a) {
@@ -291,6 +354,13 @@ extern "C" int32_t lz4mi_decompress_batch(lz4mi_ctx *c, const lz4mi_batch *b, in
 extern "C" int32_t lz4mi_set_decode_form(int32_t form) {
   if (form < 0 || form > 2) return -1;
   return set_decode_form(form);
+}
+
+extern "C" int32_t lz4mi_ctx_set_decode_form(lz4mi_ctx *c, int32_t form) {
+  if (!c || form < -1 || form > 2) return -2;
+  const int32_t prev = c->decode_form;
+  c->decode_form = form;
+  return prev;
 }
 
 extern "C" int32_t lz4mi_decompress_batch_static(lz4mi_ctx *c, const lz4mi_batch *b, int32_t strict) {

@@ -48,6 +48,7 @@ struct lz4mi_ctx {
 
   uint32_t *d_counters = nullptr;  // work-queue heads, one per launch kind
   uint32_t *static_scratch = nullptr;  // this device's address of the library's static scratch array
+  int decode_form = -1;                // lz4mi_ctx_set_decode_form: 0, 1, 2, or negative = the process default
 
   // fast/HC encoder hash tables: one 65536-entry slot per resident wavefront
   lz4mi::DevBuf tables, slot_gen, dict_table, dict_copy;
@@ -75,6 +76,11 @@ struct lz4mi_ctx {
 
   void *h_pin = nullptr;  // pinned host scratch for small read-backs
   size_t h_pin_cap = 0;
+
+  // Second stream for work that depends only on a call's input and runs beside its block launches (the
+  // single-stream content checksum of a device-resident source); created on first use.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t side_fork = nullptr, side_join = nullptr;
 };
 
 namespace lz4mi {
@@ -116,5 +122,7 @@ int32_t run_compress_fast(lz4mi_ctx *c, const BatchArgs &a, int64_t acceleration
 int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a, int64_t depth);
 int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict);
 int32_t pin_reserve(lz4mi_ctx *c, size_t n);
+// makes the side stream and its two events
+int32_t side_stream_ready(lz4mi_ctx *c);
 
 }  // namespace lz4mi

@@ -2,6 +2,8 @@
 // size words; every per-block loop body of the reference's dispatchers
 // (lib/src/frame/lz4_frame_encoder.dart:154-261, lz4_frame_decoder.dart:238-304)
 // runs as batched kernels over all blocks of the frame.
+#include <future>
+
 #include "api_common.h"
 #include "frame_host.h"
 
@@ -240,26 +242,44 @@ extern "C" int32_t lz4mi_frame_shard_write(lz4mi_ctx *c, const uint8_t *d_src, u
   return st;
 }
 
-extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
-                                             const lz4mi_frame_options *o, const uint8_t *d_dict,
-                                             uint32_t dict_len, uint8_t *d_dst, uint64_t cap, uint64_t *out_len) {
-  if (!c) return LZ4MI_RANGE;
-  int32_t st = validate_options(o);
-  if (st) return st;
-  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+namespace lz4mi {
+
+// host_hash: the content checksum when the caller computes it itself from a host copy of the bytes (on a host
+// thread, beside this call's GPU work); null: the source is only on the device and the single-stream kernel
+// hashes it on the context's side stream, beside the block launches (it depends on nothing but d_src).
+static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4mi_frame_options *o,
+                                        const uint8_t *d_dict, uint32_t dict_len, uint8_t *d_dst, uint64_t cap,
+                                        uint64_t *out_len, std::future<uint32_t> *host_hash) {
   if (cap < lz4mi_frame_bound((size_t)n, o)) return LZ4MI_DST_TOO_SMALL;
   uint8_t hdr[32];
   const size_t hlen = build_header(o, hdr);
-  st = pin_reserve(c, 256);
+  int32_t st = pin_reserve(c, 256);
   if (st) return st;
   memcpy(c->h_pin, hdr, hlen);
   LZ4MI_HIP(c, hipMemcpyAsync(d_dst, c->h_pin, hlen, hipMemcpyHostToDevice, c->stream));
   LZ4MI_HIP(c, c->words.ensure(64));
-  if (o->content_checksum)  // Xxh32 over all uncompressed content (:148,163,266)
-    launch_xxh32_serial(d_src, n, 0, c->words.as<uint32_t>(), c->stream);
+  const bool side = o->content_checksum && !host_hash;
+  if (side) {  // Xxh32 over all uncompressed content (:148,163,266)
+    st = side_stream_ready(c);
+    if (st) return st;
+    LZ4MI_HIP(c, hipEventRecord(c->side_fork, c->stream));  // whatever produced d_src on this stream is done
+    LZ4MI_HIP(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+    launch_xxh32_serial(d_src, n, 0, c->words.as<uint32_t>(), c->side_stream);
+    LZ4MI_HIP(c, hipGetLastError());
+    LZ4MI_HIP(c, hipEventRecord(c->side_join, c->side_stream));
+  }
   uint64_t body_end = 0;
   st = encode_records(c, d_src, n, o, d_dict, dict_len, d_dst, hlen, &body_end);
+  if (side) {  // also on a failure: nothing of this call stays behind on the side stream
+    const hipError_t e = hipStreamWaitEvent(c->stream, c->side_join, 0);
+    if (!st) LZ4MI_HIP(c, e);
+  }
   if (st) return st;
+  if (o->content_checksum && host_hash) {
+    uint32_t *h = (uint32_t *)((uint8_t *)c->h_pin + 64);
+    *h = host_hash->get();
+    LZ4MI_HIP(c, hipMemcpyAsync(c->words.p, h, 4, hipMemcpyHostToDevice, c->stream));
+  }
   // end mark (:263) [+ content checksum] behind the last record
   launch_put_words(d_dst + body_end, c->words.as<uint32_t>(), o->content_checksum ? 1 : 0, true, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
@@ -267,6 +287,18 @@ extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src,
   // raised after all the work, like the reference (:269-271): the frame is in d_dst, *out_len is set
   if (o->has_content_size && n != o->content_size) return LZ4MI_FORMAT_CONTENT_SIZE_ARG;
   return LZ4MI_OK;
+}
+
+}  // namespace lz4mi
+
+extern "C" int32_t lz4mi_frame_encode_device(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n,
+                                             const lz4mi_frame_options *o, const uint8_t *d_dict,
+                                             uint32_t dict_len, uint8_t *d_dst, uint64_t cap, uint64_t *out_len) {
+  if (!c) return LZ4MI_RANGE;
+  int32_t st = validate_options(o);
+  if (st) return st;
+  LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  return frame_encode_device_impl(c, d_src, n, o, d_dict, dict_len, d_dst, cap, out_len, nullptr);
 }
 
 extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n, const lz4mi_frame_options *o,
@@ -277,6 +309,10 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   int32_t st = validate_options(o);
   if (st) return st;
   LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  // The source is host memory: its content checksum (one serial chain of rounds, :148,163,266) runs on a host
+  // thread while the GPU compresses the blocks.  The future's destructor joins the thread on every return path.
+  std::future<uint32_t> content_hash;
+  if (o->content_checksum) content_hash = std::async(std::launch::async, [src, n] { return xxh32_host(src, n); });
   const size_t fb = lz4mi_frame_bound(n, o);
   LZ4MI_HIP(c, c->in.ensure(n + 16));
   LZ4MI_HIP(c, c->out.ensure(fb + 16));
@@ -290,8 +326,8 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
     dict_len = 0;
   }
   uint64_t total = 0;
-  st = lz4mi_frame_encode_device(c, c->in.as<uint8_t>(), n, o, d_dict, (uint32_t)dict_len, c->out.as<uint8_t>(),
-                                 fb, &total);
+  st = frame_encode_device_impl(c, c->in.as<uint8_t>(), n, o, d_dict, (uint32_t)dict_len, c->out.as<uint8_t>(), fb,
+                                &total, o->content_checksum ? &content_hash : nullptr);
   if (st && st != LZ4MI_FORMAT_CONTENT_SIZE_ARG) return st;
   if (total > cap) return LZ4MI_DST_TOO_SMALL;
   LZ4MI_HIP(c, hipMemcpyAsync(dst, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
@@ -377,15 +413,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   *out_len = 0;
   if (nb == 0) {
     if (walk_err) return walk_err;
-    if (want_content_hash) {
-      LZ4MI_HIP(c, c->words.ensure(64));
-      int32_t st = pin_reserve(c, 64);
-      if (st) return st;
-      launch_xxh32_serial(nullptr, 0, 0, c->words.as<uint32_t>(), c->stream);
-      LZ4MI_HIP(c, hipMemcpyAsync(c->h_pin, c->words.p, 4, hipMemcpyDeviceToHost, c->stream));
-      LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-      *content_hash = *(uint32_t *)c->h_pin;
-    }
+    if (want_content_hash) *content_hash = xxh32_host(nullptr, 0);
     return LZ4MI_OK;
   }
   LZ4MI_HIP(c, c->in.ensure(region_len + 16));
@@ -601,14 +629,33 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     extras->good_blocks = good;
     extras->sizes.assign(h_olen, h_olen + good);
   }
-  if (want_content_hash) {  // xxh32(frameOut) :306-315
-    LZ4MI_HIP(c, c->words.ensure(64));
-    launch_xxh32_serial(d_frame_out, produced, 0, c->words.as<uint32_t>(), c->stream);
-    LZ4MI_HIP(c, hipMemcpyAsync((uint8_t *)c->h_pin + hb, c->words.p, 4, hipMemcpyDeviceToHost, c->stream));
+  if (want_content_hash) {
+    // xxh32(frameOut) :306-315.  The output goes to host memory anyway: it is downloaded in pieces and a host
+    // thread hashes piece k while piece k + 1 is on its way (one serial chain of rounds; a CPU core runs it
+    // several times faster than one GPU wavefront, and beside the copy instead of in front of it).
+    lz4mi_xxh32_state hs;
+    lz4mi_xxh32_state_init(&hs, 0);
+    std::future<void> hashing;
+    const size_t piece = 32u << 20;
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < produced && e == hipSuccess; off += piece) {
+      const size_t m = produced - off < piece ? (size_t)(produced - off) : piece;
+      e = hipMemcpyAsync(dst + off, d_frame_out + off, m, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (hashing.valid()) hashing.get();
+      if (e == hipSuccess) {
+        lz4mi_xxh32_state *hp = &hs;
+        const uint8_t *q = dst + off;
+        hashing = std::async(std::launch::async, [hp, q, m] { xxh_state_update_host(hp, q, m); });
+      }
+    }
+    if (hashing.valid()) hashing.get();
+    LZ4MI_HIP(c, e);
+    *content_hash = lz4mi_xxh32_state_digest(&hs);
+  } else {
+    if (produced) LZ4MI_HIP(c, hipMemcpyAsync(dst, d_frame_out, produced, hipMemcpyDeviceToHost, c->stream));
+    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
   }
-  if (produced) LZ4MI_HIP(c, hipMemcpyAsync(dst, d_frame_out, produced, hipMemcpyDeviceToHost, c->stream));
-  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
-  if (want_content_hash) *content_hash = *(uint32_t *)((uint8_t *)c->h_pin + hb);
   if (extras) extras->d_out = d_frame_out;
   *out_len = produced;
   return LZ4MI_OK;

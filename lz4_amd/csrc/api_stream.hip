@@ -2,6 +2,7 @@
 // legacy frames) and the chunk-at-a-time frame encoder / decoder.  The per-block work is the
 // same batched kernels the one-shot frame calls use; this file is the buffering around them.
 #include <algorithm>
+#include <future>
 #include <new>
 
 #include "api_common.h"
@@ -79,6 +80,55 @@ int32_t xxh_state_update(lz4mi_ctx *c, lz4mi_xxh32_state *s, const uint8_t *data
     s->mem_size = (uint32_t)len;
   }
   return LZ4MI_OK;
+}
+
+// The same update with the whole-stripe rounds (:83-118) on the calling thread.  For content checksums of
+// bytes that are in host memory anyway (host-buffer frame calls, the stream transformers): one serial stream
+// of dependent rounds is what a CPU core does several times faster than one GPU wavefront, and on a host
+// thread it runs beside the GPU's block work instead of in line with it.
+void xxh_state_update_host(lz4mi_xxh32_state *s, const uint8_t *data, size_t len) {
+  if (len == 0) return;
+  s->total_len += len;
+  size_t p = 0;
+  if (s->mem_size + len < 16) {
+    memcpy(s->mem + s->mem_size, data, len);
+    s->mem_size += (uint32_t)len;
+    return;
+  }
+  uint32_t v0 = s->v[0], v1 = s->v[1], v2 = s->v[2], v3 = s->v[3];
+  if (s->mem_size) {
+    const size_t fill = 16 - s->mem_size;
+    memcpy(s->mem + s->mem_size, data, fill);
+    p += fill;
+    len -= fill;
+    s->mem_size = 0;
+    v0 = rotl(v0 + rd32(s->mem) * P2, 13) * P1;
+    v1 = rotl(v1 + rd32(s->mem + 4) * P2, 13) * P1;
+    v2 = rotl(v2 + rd32(s->mem + 8) * P2, 13) * P1;
+    v3 = rotl(v3 + rd32(s->mem + 12) * P2, 13) * P1;
+  }
+  const uint8_t *q = data + p, *const end = q + (len & ~(size_t)15);
+  for (; q < end; q += 16) {
+    uint32_t w[4];
+    memcpy(w, q, 16);  // little-endian host
+    v0 = rotl(v0 + w[0] * P2, 13) * P1;
+    v1 = rotl(v1 + w[1] * P2, 13) * P1;
+    v2 = rotl(v2 + w[2] * P2, 13) * P1;
+    v3 = rotl(v3 + w[3] * P2, 13) * P1;
+  }
+  s->v[0] = v0; s->v[1] = v1; s->v[2] = v2; s->v[3] = v3;
+  len &= 15;
+  if (len) {
+    memcpy(s->mem, q, len);
+    s->mem_size = (uint32_t)len;
+  }
+}
+
+uint32_t xxh32_host(const uint8_t *data, size_t len) {
+  lz4mi_xxh32_state s;
+  lz4mi_xxh32_state_init(&s, 0);
+  xxh_state_update_host(&s, data, len);
+  return lz4mi_xxh32_state_digest(&s);
 }
 
 }  // namespace lz4mi
@@ -348,9 +398,16 @@ extern "C" int32_t lz4mi_frame_encoder_update(lz4mi_frame_encoder *e, const uint
   if (st) return st;
   uint8_t *d_chunk = e->buf + kHistoryWindow + e->pending;
   LZ4MI_HIP(c, hipMemcpyAsync(d_chunk, chunk, n, hipMemcpyHostToDevice, c->stream));
-  if (e->o.content_checksum) {  // :168-170
-    st = xxh_state_update(c, &e->hasher, chunk, d_chunk, n);
-    if (st) return st;
+  // :168-170: the chunk is host memory; its content-checksum rounds run on a host thread while the GPU encodes
+  // the blocks this chunk completes (joined before the call returns, on every path)
+  struct Join {
+    std::future<void> f;
+    ~Join() { if (f.valid()) f.wait(); }
+  } hashing;
+  if (e->o.content_checksum) {
+    lz4mi_xxh32_state *hs = &e->hasher;
+    if (n >= (256u << 10)) hashing.f = std::async(std::launch::async, [hs, chunk, n] { xxh_state_update_host(hs, chunk, n); });
+    else xxh_state_update_host(hs, chunk, n);
   }
   e->pending += n;
   const size_t full = e->pending / e->bmax * e->bmax;  // :175-200, all completed blocks at once
@@ -536,7 +593,8 @@ int32_t dec_blocks(Dec *d, uint8_t *dst, size_t cap, size_t *out_len) {
   if (st) return dec_fail(d, st);
   if (produced) {
     if (d->content_ck) {  // _contentHasher.update(produced) :525
-      st = xxh_state_update(d->c, &d->hasher, dst, ex.d_out, produced);
+      xxh_state_update_host(&d->hasher, dst, produced);  // the bytes were just delivered into host memory
+      st = LZ4MI_OK;
       if (st) return dec_fail(d, st);
     }
     if (!d->indep) dec_append_history(d, dst, produced);

@@ -1837,8 +1837,8 @@ static uint32_t resident_per_cu(K kernel, int threads) {
   return (uint32_t)n;
 }
 
-void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
-                   uint32_t cu_count, hipStream_t s) {
+hipError_t launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
+                         uint32_t cu_count, int form, hipStream_t s) {
   // as many workgroups as stay resident (one that is not would hold its first block back)
   static const uint32_t per_cu[4] = {resident_per_cu(decode_kernel<false, false>, 128), resident_per_cu(decode_kernel<false, true>, 128),
                                      resident_per_cu(decode_kernel<true, false>, 128), resident_per_cu(decode_kernel<true, true>, 128)};
@@ -1850,7 +1850,7 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
     const char *e = getenv("LZ4MI_DEC_MIX");
     return e ? atoi(e) : -1;
   }();
-  const int form_env = g_decode_form.load(std::memory_order_relaxed);
+  const int form_env = form >= 0 ? form : g_decode_form.load(std::memory_order_relaxed);
   const bool pre = a.dict_len != 0;
   const uint32_t v = (strict ? 2 : 0) + (pre ? 1 : 0);
   // Few blocks (every one gets a resident pair of wavefronts): two wavefronts per block, each block done sooner.
@@ -1868,7 +1868,8 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
     if (mix == 0 && a.nblocks <= kOrderSmallMax) {
       hipLaunchKernelGGL(decode_order_small_kernel, dim3(1), dim3(1024), 0, s, a, counter, order);
     } else {
-      (void)hipMemsetAsync(counter, 0, (size_t)((order_cnt + 2) - counter) * sizeof(uint32_t), s);
+      // a fill that is refused (a stream that cannot take it) must not be followed by a launch that pops a stale queue head
+      if (hipError_t e = hipMemsetAsync(counter, 0, (size_t)((order_cnt + 2) - counter) * sizeof(uint32_t), s)) return e;
       uint32_t *tag = order + a.nblocks;
       const dim3 g((a.nblocks + 255) / 256), blk(256);
       hipLaunchKernelGGL(decode_order_count_kernel, g, blk, 0, s, a, order_cnt, tag);
@@ -1876,8 +1877,9 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
     }
   } else {
     order = nullptr;
-    (void)hipMemsetAsync(counter, 0, sizeof(uint32_t), s);
+    if (hipError_t e = hipMemsetAsync(counter, 0, sizeof(uint32_t), s)) return e;
   }
+  if (hipError_t e = hipGetLastError()) return e;  // the order kernels
   dim3 g(grid), blk(128);
   if (pair) {
     if (strict) {
@@ -1894,6 +1896,7 @@ void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t 
     if (pre) hipLaunchKernelGGL((decode_kernel<false, true>), g, blk, 0, s, a, counter, order);
     else hipLaunchKernelGGL((decode_kernel<false, false>), g, blk, 0, s, a, counter, order);
   }
+  return hipGetLastError();
 }
 
 }  // namespace lz4mi

@@ -539,28 +539,53 @@ int32_t run_compress_hc(lz4mi_ctx *c, const BatchArgs &a_in, int64_t depth) {
   uint64_t max_len = a.src_len ? (a.dst_cap_uniform ? a.dst_cap_uniform : (4u << 20)) : a.src_len_uniform;
   if (max_len > 0x7FFFFFF0u) max_len = 0x7FFFFFF0u;
   const uint64_t stride = round_up(max_len + (a.linked ? 65535u : a.dict_len) + 64, 64);
-  const uint64_t budget = 8ull << 30;  // bytes of index scratch
+  // Index scratch: 20 bytes per position and slot.  Up to 8 GiB in all for a batch; a call whose single
+  // slot needs more (one block of 400 MiB and more) may take what the device has free, and one that does not
+  // fit there either is refused with the reason instead of failing inside hipMalloc.
+  const uint64_t per_slot = stride * 20;
+  uint64_t budget = 8ull << 30;
+  if (per_slot > budget) {
+    size_t free_b = 0, total_b = 0;
+    LZ4MI_HIP(c, hipMemGetInfo(&free_b, &total_b));
+    const uint64_t have = (uint64_t)free_b + c->hc_chain.cap;  // what a regrown buffer could take
+    if (per_slot + (1ull << 30) > have) {
+      c->err = "LZ4HC index of one block of " + std::to_string(max_len) + " bytes needs " + std::to_string(per_slot) +
+               " bytes of device scratch, " + std::to_string(have) + " are free";
+      return LZ4MI_UNSUPPORTED_HERE;
+    }
+    budget = per_slot;
+  }
   const uint32_t max_slots = (uint32_t)c->cu_count * 4u * LZ4MI_HC_WPE;  // the wavefronts that stay resident
-  uint32_t slots = (uint32_t)round_up(a.nblocks < max_slots ? a.nblocks : max_slots, 4);
-  while (slots > 4 && (uint64_t)slots * stride * 20 > budget) slots -= 4;
-  const size_t tbl = (size_t)slots * kHashEntries * sizeof(uint32_t);
+  const uint32_t want = a.nblocks < max_slots ? a.nblocks : max_slots;
+  const uint32_t fit = (uint32_t)(budget / per_slot < max_slots ? budget / per_slot : max_slots);  // >= 1
+  // wavefronts per workgroup: four, fewer when fewer blocks or slots than that exist
+  uint32_t wpw = 4, slots;
+  if (want < 4 || fit < 4) {
+    slots = wpw = want < fit ? want : fit;
+  } else {
+    slots = (uint32_t)round_up(want, 4);
+    if (slots > fit) slots = fit & ~3u;
+  }
+  // a launch with a wavefront per block leaves the slots behind the last block untouched: no memory for them
+  const uint32_t mem_slots = slots < a.nblocks ? slots : a.nblocks;
+  const size_t tbl = (size_t)mem_slots * kHashEntries * sizeof(uint32_t);
   LZ4MI_HIP(c, c->hc_floor.ensure(tbl));
-  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)slots * stride * 20));
+  LZ4MI_HIP(c, c->hc_chain.ensure((size_t)mem_slots * per_slot));
   HcScratch sc;
   sc.floor_ = c->hc_floor.as<uint32_t>();
   sc.index = c->hc_chain.as<uint32_t>();
   sc.stride = stride;
   uint32_t *counter = c->d_counters + 5;  // word 5: HC queue head (0-2 decode, 4 fast encode)
   LZ4MI_HIP(c, hipMemsetAsync(counter, 0, sizeof(uint32_t), c->stream));
-  uint32_t grid = (a.nblocks + 3) / 4;
-  if (grid > slots / 4) grid = slots / 4;
+  const uint32_t grid = slots / wpw;
+  const dim3 wg(wpw * kWave);
   uint32_t d32 = depth > 0x7fffffff ? 0x7fffffffu : (uint32_t)depth;
   if (a.linked)
-    hipLaunchKernelGGL((encode_hc_kernel<true, true>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+    hipLaunchKernelGGL((encode_hc_kernel<true, true>), dim3(grid), wg, 0, c->stream, a, d32, sc, counter);
   else if (a.dict_len)
-    hipLaunchKernelGGL((encode_hc_kernel<true, false>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+    hipLaunchKernelGGL((encode_hc_kernel<true, false>), dim3(grid), wg, 0, c->stream, a, d32, sc, counter);
   else
-    hipLaunchKernelGGL((encode_hc_kernel<false, false>), dim3(grid), dim3(256), 0, c->stream, a, d32, sc, counter);
+    hipLaunchKernelGGL((encode_hc_kernel<false, false>), dim3(grid), wg, 0, c->stream, a, d32, sc, counter);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;
 }

@@ -78,5 +78,9 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
 // already on the device (d_data != nullptr: no upload).
 int32_t xxh_state_update(lz4mi_ctx *c, lz4mi_xxh32_state *s, const uint8_t *data, const uint8_t *d_data,
                          size_t len);
+// Xxh32.update / xxh32 entirely on the calling thread: content checksums of bytes that lie in host memory
+// (lz4_frame_encoder.dart:148,163,266; lz4_frame_decoder.dart:306-315), run on a host thread beside the GPU work.
+void xxh_state_update_host(lz4mi_xxh32_state *s, const uint8_t *data, size_t len);
+uint32_t xxh32_host(const uint8_t *data, size_t len);
 
 }  // namespace lz4mi

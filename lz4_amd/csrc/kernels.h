@@ -73,10 +73,12 @@ struct ChainArgs {
 void launch_decode_chain(const ChainArgs &c, hipStream_t s);
 // counter: the queue head; order: TWO words per block (queue order, and scratch for building it), or null:
 // index order; order_cnt: two words behind counter in the same array.  The launch zeroes the words it uses (on s).
-// The grid is sized to the wavefronts that stay resident.
-void launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
-                   uint32_t cu_count, hipStream_t s);
-// 0: by launch size, 1: one wavefront per block, 2: two wavefronts per block; returns the previous setting
+// The grid is sized to the wavefronts that stay resident.  form: 0 by launch size, 1 one wavefront per block,
+// 2 two wavefronts per block, negative: the process default (set_decode_form).  Returns the first error of
+// the fills and launches it issued.
+hipError_t launch_decode(const BatchArgs &a, bool strict, uint32_t *counter, uint32_t *order_cnt, uint32_t *order,
+                         uint32_t cu_count, int form, hipStream_t s);
+// process default of the decode form (0, 1, 2 as above); returns the previous setting
 int set_decode_form(int form);
 void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeScratch &sc, uint32_t *counter,
                         uint32_t grid, hipStream_t s);

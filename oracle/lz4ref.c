@@ -1755,3 +1755,38 @@ int lz4ref_block_conformant(const uint8_t *src, size_t c) {
   }
   return !(nmatch && (trailing < 5 || last_start + 12 > op));
 }
+
+/* Harness helpers (no reference counterpart): the per-block calls above over a run of equal-sized blocks, so that
+ * a host thread spends its time in the codec and not in the caller's per-call overhead.  Block b reads
+ * src + b * block and writes comp + b * comp_stride; sizes[b] receives / gives its compressed length. */
+int lz4ref_blocks_compress(const uint8_t *src, size_t nblocks, size_t block, const uint8_t *dict, size_t dict_len,
+                           int level, int64_t param, uint8_t *comp, size_t comp_stride, int64_t *sizes) {
+  for (size_t b = 0; b < nblocks; b++) {
+    size_t n = 0;
+    int st = lz4ref_block_compress_ex(src + b * block, block, dict, dict_len, level, param, 0, comp + b * comp_stride,
+                                      comp_stride, &n);
+    if (st) return st;
+    sizes[b] = (int64_t)n;
+  }
+  return LZ4REF_OK;
+}
+
+/* dict_len == 0: strict decode of every block to exactly `block` bytes (lz4BlockDecompress).  Otherwise the way the
+ * frame decoder takes a block behind a dictionary (lz4_frame_decoder.dart:273-290): lenient decode behind the
+ * prefix in `tmp` (dict_len + block bytes, prefix already in place), then the block's bytes are copied out. */
+int lz4ref_blocks_decompress(const uint8_t *comp, size_t comp_stride, const int64_t *sizes, size_t nblocks, size_t block,
+                             uint8_t *tmp, size_t dict_len, uint8_t *out) {
+  for (size_t b = 0; b < nblocks; b++) {
+    if (!dict_len) {
+      int st = lz4ref_block_decompress(comp + b * comp_stride, (size_t)sizes[b], out + b * block, (int64_t)block);
+      if (st) return st;
+    } else {
+      size_t n = 0;
+      int st = lz4ref_block_decompress_into(comp + b * comp_stride, (size_t)sizes[b], tmp, dict_len, dict_len + block, &n);
+      if (st) return st;
+      if (n != dict_len + block) return LZ4REF_CORRUPT_CONTENT_SIZE;
+      memcpy(out + b * block, tmp + dict_len, block);
+    }
+  }
+  return LZ4REF_OK;
+}

@@ -208,6 +208,14 @@ void lz4ref_stream_decoder_free(lz4ref_stream_decoder *d);
  * end-of-block rules, 0 when it ends the way the reference's encoders allow (lz4_block_encoder.dart:95,118). */
 int lz4ref_block_conformant(const uint8_t *src, size_t c);
 
+/* Harness helpers (no reference counterpart): the per-block calls over a run of equal-sized blocks in one call
+ * (level 0 fast / 1 hc as in lz4ref_block_compress_ex; decode strict without a dictionary, lenient behind the
+ * dictionary prefix held in tmp[0..dict_len) otherwise). */
+int lz4ref_blocks_compress(const uint8_t *src, size_t nblocks, size_t block, const uint8_t *dict, size_t dict_len,
+                           int level, int64_t param, uint8_t *comp, size_t comp_stride, int64_t *sizes);
+int lz4ref_blocks_decompress(const uint8_t *comp, size_t comp_stride, const int64_t *sizes, size_t nblocks,
+                             size_t block, uint8_t *tmp, size_t dict_len, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,10 @@ def lib():
         L.lz4ref_block_decompress_into.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                    C.c_size_t, C.POINTER(C.c_size_t)]
         L.lz4ref_block_conformant.argtypes = [C.c_char_p, C.c_size_t]
+        L.lz4ref_blocks_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int,
+                                             C.c_int64, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lz4ref_blocks_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, C.c_void_p]
         L.lz4ref_xxh32.restype = C.c_uint32
         L.lz4ref_xxh32.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         L.lz4ref_xxh32_init.argtypes = [C.POINTER(_XxhState), C.c_uint32]

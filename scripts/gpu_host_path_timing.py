@@ -9,7 +9,9 @@ L = N.load()
 ctx = N.default_context(0)
 nbytes = 256 << 20
 data = corpus(nbytes // 65536, 65536)
-o = api._c_options(Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB))
+with_ck = "ck" in sys.argv[1:]  # `ck`: contentChecksum on (hashed on a host thread beside the GPU work)
+o = api._c_options(Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, contentChecksum=with_ck))
+print("contentChecksum:", with_ck, flush=True)
 cap = L.lz4mi_frame_bound(nbytes, C.byref(o))
 dst = np.empty(cap, dtype=np.uint8)
 back = np.empty(nbytes + 64, dtype=np.uint8)

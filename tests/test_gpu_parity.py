@@ -151,14 +151,15 @@ def _mutations(rng, blocks, per_block):
 
 
 @pytest.fixture(params=[0, 1, 2], ids=["form-by-size", "one-wavefront", "two-wavefronts"])
-def decode_form(request):
-    """The decoder's two launch forms (one or two wavefronts per block): results never depend on the form."""
+def decode_form(request, codec):
+    """The decoder's two launch forms (one or two wavefronts per block): results never depend on the form.
+    The form is a setting of the context; the process default stays untouched."""
     from lz4_amd import _native as N
     L = N.load()
-    prev = L.lz4mi_set_decode_form(request.param)
-    assert prev >= 0
+    prev = L.lz4mi_ctx_set_decode_form(codec.ctx.handle, request.param)
+    assert prev >= -1
     yield request.param
-    L.lz4mi_set_decode_form(prev)
+    assert L.lz4mi_ctx_set_decode_form(codec.ctx.handle, prev) == request.param
 
 
 

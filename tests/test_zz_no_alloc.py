@@ -71,6 +71,68 @@ def test_static_decode_equals_allocating_decode():
         assert np.array_equal(o0[ok], o1[ok])
 
 
+def test_static_decode_first_call_on_a_fresh_context_allocates_nothing():
+    """The static entry point as the FIRST decode call of a context (its order buffer has never been grown), with
+    the largest batch of this file: neither the context's buffers nor the device's free memory change across the
+    call, and the result equals the allocating entry point's, which is called afterwards and does grow them."""
+    import torch
+    from lz4_amd import _native as N
+    from lz4_amd.device import DeviceCodec
+    nblocks = 9000
+    raw = corpus(nblocks, block=BLOCK, seed=7)
+    src = torch.from_numpy(raw.copy()).cuda()
+    comp, sizes, status = DeviceCodec(0).compress_blocks(src, BLOCK)  # another context does the compressing
+    torch.cuda.synchronize()
+    assert int(status.abs().sum()) == 0
+    codec = DeviceCodec(0)  # fresh: has decoded nothing
+    L = codec.L
+    outs = [(torch.zeros((nblocks, BLOCK), dtype=torch.uint8, device="cuda"),
+             torch.full((nblocks,), -1, dtype=torch.int32, device="cuda"),
+             torch.full((nblocks,), -1, dtype=torch.int32, device="cuda")) for _ in range(2)]
+    torch.cuda.synchronize()
+    held0, free0 = L.lz4mi_ctx_device_bytes(codec.ctx.handle), torch.cuda.mem_get_info()[0]
+    b = _batch(N, comp, sizes, *outs[0], True)
+    assert L.lz4mi_decompress_batch_static(codec.ctx.handle, C.byref(b), 1) == 0
+    codec.synchronize()
+    assert L.lz4mi_ctx_device_bytes(codec.ctx.handle) == held0, "the static entry point grew a context buffer"
+    assert torch.cuda.mem_get_info()[0] == free0, "device memory was allocated during the static call"
+    b = _batch(N, comp, sizes, *outs[1], True)
+    assert L.lz4mi_decompress_batch(codec.ctx.handle, C.byref(b), 1) == 0
+    codec.synchronize()
+    assert L.lz4mi_ctx_device_bytes(codec.ctx.handle) >= held0 + 2 * 4 * nblocks  # its order list: two words per block
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert np.array_equal(outs[0][0].cpu().numpy().reshape(-1), raw)
+
+
+def test_static_decode_from_two_contexts_takes_turns():
+    """Two contexts with a stream each share the GPU's scratch array: calls issued back to back without a
+    synchronisation in between are ordered by the library (event of the last user), so both come out right."""
+    import torch
+    from lz4_amd import _native as N
+    from lz4_amd.device import DeviceCodec
+    a, b_ = DeviceCodec(0), DeviceCodec(0)
+    jobs = []
+    for k, (codec, nblocks) in enumerate(((a, 6000), (b_, 7000), (a, 3000), (b_, 6500))):
+        raw = corpus(nblocks, block=BLOCK, seed=20 + k)
+        src = torch.from_numpy(raw.copy()).cuda()
+        comp, sizes, status = codec.compress_blocks(src, BLOCK)
+        out = torch.zeros((nblocks, BLOCK), dtype=torch.uint8, device="cuda")
+        out_len = torch.full((nblocks,), -1, dtype=torch.int32, device="cuda")
+        st = torch.full((nblocks,), -1, dtype=torch.int32, device="cuda")
+        jobs.append((codec, raw, comp, sizes, out, out_len, st))
+    torch.cuda.synchronize()
+    for codec, raw, comp, sizes, out, out_len, st in jobs:  # all four enqueued before anything is waited for
+        bt = _batch(N, comp, sizes, out, out_len, st, True)
+        assert codec.L.lz4mi_decompress_batch_static(codec.ctx.handle, C.byref(bt), 1) == 0
+    a.synchronize()
+    b_.synchronize()
+    for codec, raw, comp, sizes, out, out_len, st in jobs:
+        assert not st.cpu().numpy().any()
+        assert (out_len.cpu().numpy() == BLOCK).all()
+        assert np.array_equal(out.cpu().numpy().reshape(-1), raw)
+
+
 def test_static_decode_rejects_more_blocks_than_its_scratch_holds():
     import torch
     from lz4_amd import _native as N
