@@ -114,8 +114,9 @@ def load():
         L.lz4mi_ctx_destroy.argtypes = [vp]
         L.lz4mi_ctx_destroy.restype = None
         L.lz4mi_ctx_synchronize.argtypes = [vp]
-        L.lz4mi_ctx_device_bytes.restype = u64
-        L.lz4mi_ctx_device_bytes.argtypes = [vp]
+        if not os.environ.get("LZ4MI_LIB") or hasattr(L, "lz4mi_ctx_device_bytes"):  # an older build under LZ4MI_LIB (A/B timing) may lack it
+            L.lz4mi_ctx_device_bytes.restype = u64
+            L.lz4mi_ctx_device_bytes.argtypes = [vp]
         L.lz4mi_last_backend_error.restype = C.c_char_p
         L.lz4mi_last_backend_error.argtypes = [vp]
         L.lz4mi_compress_bound.restype = sz
@@ -130,7 +131,8 @@ def load():
         L.lz4mi_decompress_batch.argtypes = [vp, C.POINTER(Batch), i32]
         L.lz4mi_decompress_batch_static.argtypes = [vp, C.POINTER(Batch), i32]
         L.lz4mi_set_decode_form.argtypes = [i32]
-        L.lz4mi_ctx_set_decode_form.argtypes = [C.c_void_p, i32]
+        if not os.environ.get("LZ4MI_LIB") or hasattr(L, "lz4mi_ctx_set_decode_form"):
+            L.lz4mi_ctx_set_decode_form.argtypes = [C.c_void_p, i32]
         L.lz4mi_xxh32_batch.argtypes = [vp, C.POINTER(Batch), vp]
         L.lz4mi_xxh32_device.argtypes = [vp, vp, u64, u32, vp]
         L.lz4mi_frame_options_default.argtypes = [C.POINTER(FrameOptions)]

@@ -29,6 +29,10 @@ namespace lz4mi {
 
 #ifdef LZ4MI_PROFILE
 __device__ unsigned long long g_enc_phase[PH_SLOTS];
+__device__ unsigned long long g_fast_exit[16];  // how often the short path left at each of its exits
+#define FAST_EXIT(k) do { if (lane == 0) atomicAdd(&g_fast_exit[k], 1ull); } while (0)
+#else
+#define FAST_EXIT(k) do {} while (0)
 #endif
 #if defined(LZ4MI_PROFILE) || defined(LZ4MI_SPANS)
 #define LZ4MI_ENC_SPANS 1
@@ -218,19 +222,35 @@ __device__ __forceinline__ uint32_t shr_min(uint32_t h) {
 }
 
 // Writing a sequence (_writeSequence, :172-200) is not on the path to the next match, so it is taken
-// off the serial chain: a found sequence is noted in LDS (literal start, literal length, distance,
-// match length) and up to kBatch of them are written together.  Lane j sizes sequence j, a prefix
+// off the serial chain: a found sequence is noted down (literal start, literal length, distance, match
+// length: four registers, sequence j of the batch in lane j, written with v_writelane) and up to kBatch
+// of them are written together.  Lane j sizes sequence j, a prefix
 // sum places it, the lane writes its token, length bytes and offset; the literal runs follow one
 // after the other, wave-wide, out of the input ring when it still holds them.
 constexpr uint32_t kBatch = 32;
-__device__ __forceinline__ uint32_t write_sequences(const Win &w, lds_u32 *desc, uint32_t cnt, uint8_t *out, uint32_t op,
+struct SeqBatch {  // lane j holds sequence j of the batch
+  uint32_t s, lit, dist, ml;
+};
+// Lane l of the four registers takes a sequence's four (wave-uniform) fields: v_writelane_b32, no exec masking.
+// The lane number travels in m0 (an instruction reads one scalar register besides m0), which is handed back
+// as it was found.
+__device__ __forceinline__ void put_seq(SeqBatch &q, uint32_t s, uint32_t lit, uint32_t dist, uint32_t ml, uint32_t l) {
+  uint32_t keep;
+  asm("s_mov_b32 %4, m0\n\t"
+      "s_mov_b32 m0, %9\n\t"
+      "s_nop 0\n\t"
+      "v_writelane_b32 %0, %5, m0\n\t"
+      "v_writelane_b32 %1, %6, m0\n\t"
+      "v_writelane_b32 %2, %7, m0\n\t"
+      "v_writelane_b32 %3, %8, m0\n\t"
+      "s_mov_b32 m0, %4"
+      : "+v"(q.s), "+v"(q.lit), "+v"(q.dist), "+v"(q.ml), "=&s"(keep)
+      : "s"(uni(s)), "s"(uni(lit)), "s"(uni(dist)), "s"(uni(ml)), "s"(uni(l)));  // uni: free for values that are scalar already
+}
+__device__ __forceinline__ uint32_t write_sequences(const Win &w, const SeqBatch &q, uint32_t cnt, uint8_t *out, uint32_t op,
                                                     uint32_t lane) {
   const bool mine = lane < cnt;
-  uint32_t s = 0, lit = 0, dist = 0, ml = 4;
-  if (mine) {
-    const u32x4 d = *(lds_u128 *)(desc + 4 * lane);
-    s = d.x; lit = d.y; dist = d.z; ml = d.w;
-  }
+  const uint32_t s = mine ? q.s : 0u, lit = mine ? q.lit : 0u, dist = mine ? q.dist : 0u, ml = mine ? q.ml : 4u;
   const uint32_t m4 = ml - 4;
   const uint32_t e1 = lit >= 15 ? (lit - 15) / 255u + 1u : 0u;  // _writeLength :216-223: v / 255 bytes of 255, then v % 255
   const uint32_t mx = m4 >= 15 ? (m4 - 15) / 255u + 1u : 0u;
@@ -269,6 +289,148 @@ __device__ __forceinline__ uint32_t write_sequences(const Win &w, lds_u32 *desc,
   return op + rdlane(incl, kWave - 1);
 }
 
+// Interior re-hash of a match (:135-145) that started at ms and ended at `anchor` (exclusive): of the positions
+// ms+1 .. anchor-4 only the last `dist` can survive in the table (position j and j + dist hash the same bytes and
+// j + dist is inserted later).
+template <bool HAS_DICT>
+__device__ __forceinline__ void rehash_match(const EncIn &in, const Win &w, uint32_t *T, lds_u32 *claim, uint32_t gtag,
+                                             uint32_t ms, uint32_t dist, uint32_t anchor, uint32_t lane) {
+  const uint32_t D = HAS_DICT ? in.D : 0u;
+  if (anchor + 4 <= in.plimit) {
+    const uint32_t hi = anchor - 4;
+    uint32_t lo = ms + 1;
+    if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
+    if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
+      for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        insert_step(T, claim, hash16(w32(w, j - D)), gtag | (j + 1), j <= hi, lane);
+      }
+    } else {
+      for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
+        const uint32_t j = j0 + lane;
+        if (j <= hi) tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
+      }
+      vm_quiesce();  // rare path: leave no load pending at the join
+    }
+  }
+}
+
+// Lane masks straight from a compare (a ballot of a bool costs a select and a second compare on the way).
+__device__ __forceinline__ uint64_t m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ __forceinline__ uint64_t m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ __forceinline__ uint64_t m_uge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
+__device__ __forceinline__ uint64_t m_ult(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+__device__ __forceinline__ uint64_t m_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+
+// One sequence the short way, for blocks without a dictionary: every assumption of the common case is checked
+// on the way and nothing is written before the last of them holds, so a `false` leaves the state as it was and
+// the general code below takes the sequence from its start.  The common case: the ring holds what the sequence
+// reads and no segment is due; all kFirst probes lie in front of the last searched position; no two of them
+// meet in a slot of the vote array (so no two share a bucket); one of them hits; the reference lies inside the
+// ring with the margins of the one-round-trip extension; the match is shorter than 32 bytes backwards and 256
+// forwards.  What it does is what the general code does (same reads, same table writes, same sequence).
+__device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t *T, lds_u32 *claim, uint32_t gen,
+                                              uint32_t offP, uint32_t ext_off, uint32_t ext_need, uint32_t lane,
+                                              uint32_t &anchor, SeqBatch &batch, uint32_t &nbatch, uint32_t &op,
+                                              uint8_t *out) {
+  const uint32_t n = in.total, plimit = in.plimit, elimit = in.elimit;
+  const uint32_t s = anchor;
+  const uint32_t gtag = gen << kPosBits;
+  {
+    const uint32_t need = s + kLead < n ? s + kLead : n;
+    if (s < w.lo || w.hi < need) { FAST_EXIT(1); return false; }
+    if (s + 128 > plimit) { FAST_EXIT(3); return false; }                      // the block's end (every probe below is a valid one)
+  }
+  // the next segment is requested together with the table gather and lands after the same wait
+  const bool pend = w.hi < n && w.hi < s + kLead + kSeg;
+  u32x4 pv = {0, 0, 0, 0};
+  if (pend) pv = seg_load(w, w.hi, lane);
+  // Lanes behind the first kFirst repeat lane 0's probe (offP is zero there): same addresses, same answers.
+  const uint32_t ik = s + offP;
+  const uint32_t seq = w32(w, ik);
+  const uint32_t h = hash16(seq);
+  const uint32_t e = tbl_load(T + h);
+  // probes that meet in a byte slot of the vote array (all zero between uses) see each other's lane number
+  uint32_t seen = lane + 1;
+  if (lane < kFirst) {
+    volatile lds_u8 *mark = (volatile lds_u8 *)claim + (h & (4 * kClaimSlots - 1));
+    *mark = (uint8_t)(lane + 1);
+    seen = *mark;
+    *mark = 0;
+  }
+  uint32_t ref = e - (gtag + 1);  // the entry's position when its generation is this block's
+  uint32_t distv = ik - ref;
+  // :102 (an entry of this block's generation lies in front of ik)
+  uint64_t cand = m_eq(e >> kPosBits, gen) & m_ule(distv, 0xFFFFu);
+  const uint64_t clash = m_ne(seen, lane + 1);
+  if (clash) {
+    // Probes that may share a bucket: an earlier probe of the run in the same bucket acts as the table entry
+    // (:99-100 in program order), the nearest one.  Frequent where the data repeats at a short distance.
+    uint32_t near = 0;
+    near = row_shr<9>(h, ~0u) == h ? 9u : near;
+    near = row_shr<8>(h, ~0u) == h ? 8u : near;
+    near = row_shr<7>(h, ~0u) == h ? 7u : near;
+    near = row_shr<6>(h, ~0u) == h ? 6u : near;
+    near = row_shr<5>(h, ~0u) == h ? 5u : near;
+    near = row_shr<4>(h, ~0u) == h ? 4u : near;
+    near = row_shr<3>(h, ~0u) == h ? 3u : near;
+    near = row_shr<2>(h, ~0u) == h ? 2u : near;
+    near = row_shr<1>(h, ~0u) == h ? 1u : near;
+    const uint32_t ikp = (uint32_t)__shfl((int)ik, (int)(lane - near));
+    const uint64_t dupl = m_ne(near, 0u);
+    cand |= dupl;
+    ref = near ? ikp : ref;
+    distv = ik - ref;
+  }
+  cand &= (1ull << kFirst) - 1ull;  // the lanes behind the probes copy lane 0: no hit of theirs counts
+  uint32_t rb = w32(w, ref);
+  const uint64_t far = cand & m_ult(ref, w.lo);
+  if (far) {  // references the ring has dropped: their bytes come from memory
+    if (__builtin_amdgcn_inverse_ballot_w64(far)) rb = ld32(in.src + ref);
+  }
+  const uint64_t hit = cand & m_eq(rb, seq);  // :103
+  if (pend) seg_store(w, w.hi, pv, lane);
+  vm_quiesce();
+  if (hit == 0) { FAST_EXIT(4); return false; }
+
+  // ---- match at lane K
+  const uint32_t K = (uint32_t)__builtin_ctzll(hit);
+  const uint32_t i = rdlane(ik, K), dist = rdlane(distv, K), r0 = i - dist;
+  const uint32_t maxb = i - anchor < r0 ? i - anchor : r0;
+  if (!(r0 >= w.lo + 32 && (i + 272 <= w.hi || w.hi >= n))) { FAST_EXIT(5); return false; }
+  // lanes 0-31 compare one byte each going backwards (:107-113), lanes 32-63 eight bytes each going forwards (:117-121)
+  const uint32_t pp = i + ext_off;
+  const uint64_t x = w64(w, pp) ^ w64(w, pp - dist);
+  const uint32_t e8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+  const uint32_t avail = pp < elimit ? elimit - pp : 0u;  // bytes past the match limit never count
+  const uint32_t eq = e8 < avail ? e8 : avail;
+  // a lane stops the run when it has fewer equal bytes than it looks at (1 backwards, 8 forwards); so does
+  // every backward lane at or past maxb
+  const uint32_t mb = maxb < 32 ? maxb : 32u;
+  const uint64_t sm = m_ult(eq, ext_need) | (0xFFFFFFFFull & ~((1ull << mb) - 1ull));
+  const uint32_t sm_lo = (uint32_t)sm, sm_hi = (uint32_t)(sm >> 32);
+  if (sm_lo == 0 || sm_hi == 0) { FAST_EXIT(6); return false; }  // longer than 32 backwards or 256 forwards
+  const uint32_t b = (uint32_t)__builtin_ctz(sm_lo);
+  const uint32_t L = (uint32_t)__builtin_ctz(sm_hi);
+  const uint32_t fwd = 8 * L + rdlane(eq, 32 + L);
+  const uint32_t ms = i - b, ml = b + 4 + fwd, lit = ms - anchor;
+
+  // ---- nothing can fail from here on: _writeSequence (deferred), :100 for the probes up to the hit, :132-145
+  put_seq(batch, s, lit, dist, ml, nbatch);
+  if (++nbatch == kBatch) {
+    op = write_sequences(w, batch, nbatch, out, op, lane);
+    nbatch = 0;
+  }
+  anchor = ms + ml;
+  if (lane <= K) {  // :100 for every probe of the step up to the hit; probes that may share a bucket take the maximum
+    if (clash) tbl_max(T + h, gtag | (ik + 1));
+    else tbl_store(T + h, gtag | (ik + 1));
+  }
+  rehash_match<false>(in, w, T, claim, gtag, ms, dist, anchor, lane);
+  FAST_EXIT(0);
+  return true;
+}
+
 // Position held by a table entry, or -1.
 template <bool WIDE>
 __device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen) {
@@ -280,8 +442,7 @@ template <bool HAS_DICT, bool LINKED, bool WIDE>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
-                                                     lds_u32 *claim, lds_u32 *desc, uint32_t lane,
-                                                     uint32_t &out_len) {
+                                                     lds_u32 *claim, uint32_t lane, uint32_t &out_len) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   const uint32_t total = in.total;
   const uint32_t plimit = in.plimit, elimit = in.elimit;
@@ -303,8 +464,18 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       }
     }
     Win w = {lds, in.src, n, 0, 0};
+    // lane constants of the one-round-trip match extension: where a lane looks relative to the hit, how many bytes
+    const uint32_t ext_off = lane < 32 ? 0u - 1u - lane : 4u + 8u * (lane - 32);
+    const uint32_t ext_need = lane < 32 ? 1u : 8u;
+    const uint32_t offP = lane < kFirst ? offA : 0u;  // probe offsets of the first step; the other lanes repeat lane 0
     uint32_t nbatch = 0;  // sequences found and not yet written
+    SeqBatch batch = {0, 0, 0, 4};
     while (anchor + 4 <= plimit) {  // one iteration per sequence
+#ifndef LZ4MI_NO_FAST_SEQ
+      if (!HAS_DICT && !LINKED && !WIDE) {
+        if (fast_sequence(in, w, T, claim, gen, offP, ext_off, ext_need, lane, anchor, batch, nbatch, op, out)) continue;
+      }
+#endif
       const uint32_t s = anchor - D;
       {
         const uint32_t need = s + kLead < n ? s + kLead : n;
@@ -341,8 +512,26 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         // Earlier probes of the run that land in the same bucket act as the table entry (:99-100
         // in program order).  Equal hashes among the first probes are rare: detect with row shifts, resolve
         // out of line.
+#ifdef LZ4MI_DUP_DPP
         const uint32_t mn = shr_min<kFirst - 1>(h);
         dup = ballot(valid && mn == 0) != 0;
+#else
+        // Every probe marks the byte slot of its hash (1024 slots in the vote array, which is all zero between
+        // uses) with its lane number and reads the slot back: two probes in one slot leave one number there, so
+        // the other lane sees it.  A shared slot is a shared bucket or two buckets that meet in the slot (one
+        // sequence in twenty); the loop below then compares the hashes themselves.  The three LDS operations
+        // ride in the shadow of the table gather.
+        {
+          volatile lds_u8 *mark = (volatile lds_u8 *)claim + (h & (4 * kClaimSlots - 1));  // volatile: what comes back is another lane's
+          uint32_t seen = lane + 1;
+          if (valid) {
+            *mark = (uint8_t)(lane + 1);
+            seen = *mark;
+            *mark = 0;
+          }
+          dup = ballot(seen != lane + 1) != 0;
+        }
+#endif
         if (dup) {
           for (uint32_t j = 0; j + 1 < nvalid; j++) {  // nearest earlier lane with an equal hash wins
             const uint32_t hj = rdlane(h, j), ij = rdlane(ik, j);
@@ -513,9 +702,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       PH(5);
 
       // ---- _writeSequence :172-200, deferred: the sequence is noted down and written with its batch
-      if (lane < 4) desc[4 * nbatch + lane] = lane == 0 ? s : lane == 1 ? lit : lane == 2 ? dist : ml;
+      put_seq(batch, s, lit, dist, ml, nbatch);
       if (++nbatch == kBatch) {
-        op = write_sequences(w, desc, nbatch, out, op, lane);
+        op = write_sequences(w, batch, nbatch, out, op, lane);
         nbatch = 0;
       }
       anchor = ms + ml;  // :132-133
@@ -529,26 +718,10 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       PH(6);
 
       // ---- :135-145 interior re-hash, last `dist` positions only
-      if (anchor + 4 <= plimit) {
-        const uint32_t hi = anchor - 4;
-        uint32_t lo = ms + 1;
-        if (anchor >= 3 + dist && anchor - 3 - dist > lo) lo = anchor - 3 - dist;
-        if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
-          for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            insert_step(T, claim, hash16(w32(w, j - D)), gtag | (j + 1), j <= hi, lane);
-          }
-        } else {
-          for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
-            const uint32_t j = j0 + lane;
-            if (j <= hi) tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
-          }
-          vm_quiesce();  // rare path: leave no load pending at the join
-        }
-      }
+      rehash_match<HAS_DICT>(in, w, T, claim, gtag, ms, dist, anchor, lane);
       PH(7);
     }
-    if (nbatch) op = write_sequences(w, desc, nbatch, out, op, lane);
+    if (nbatch) op = write_sequences(w, batch, nbatch, out, op, lane);
   }
   // _writeLastLiterals :153-156, :202-214
   const uint32_t last = total - anchor;
@@ -575,7 +748,6 @@ template <bool HAS_DICT, bool LINKED, bool WIDE = false>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[4][kClaimSlots];
-  __shared__ __attribute__((aligned(16))) uint32_t s_desc[4][4 * kBatch];
   EncodeKArgsPtr ka = (EncodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
@@ -640,8 +812,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
     if (lane == 0 && b < 65536) g_enc_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
     int32_t st = encode_block_fast<HAS_DICT, LINKED, WIDE>(in, out, cap, sh, T, dictT, gen, offA, offB,
-                                                     (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], (lds_u32 *)s_desc[wave], lane,
-                                                     out_len);
+                                                     (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane, out_len);
 #ifdef LZ4MI_ENC_SPANS
     if (lane == 0 && b < 65536) g_enc_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -677,6 +848,13 @@ extern "C" void lz4mi_debug_enc_spans(unsigned long long *out, int n) {
 }
 #endif
 #ifdef LZ4MI_PROFILE
+extern "C" void lz4mi_debug_fast_exits(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_exit), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fast_exit), z, sizeof z);
+  }
+}
 extern "C" void lz4mi_debug_enc_phases(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_phase), sizeof(unsigned long long) * PH_SLOTS);
   if (reset) {

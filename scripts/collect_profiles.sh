@@ -17,7 +17,7 @@ rm -rf $out/trace $out/pmc_fetch $out/pmc_write
 python scripts/traffic_from_pmc.py $out $out/traffic.json
 # the other bench lines of the round: one-rank rehearsal of the sharded step, configs 2 and 4, the 8 GiB shard
 LZ4MI_BENCH_DIST=1 timeout -k 10 300 python bench.py > $out/bench_dist1.json 2> $out/bench_dist1.err
-timeout -k 10 400 python bench.py --config 2 --steps 3 --warmup 1 > $out/bench_config2.json 2> $out/bench_config2.err
+timeout -k 10 400 python bench.py --config 2 --steps 8 --warmup 1 > $out/bench_config2.json 2> $out/bench_config2.err
 timeout -k 10 400 python bench.py --config 4 --steps 3 --warmup 1 > $out/bench_config4.json 2> $out/bench_config4.err
 timeout -k 10 500 python bench.py --blocks 131072 --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_8gib.json 2> $out/bench_8gib.err
 LZ4MI_BENCH_DIST=1 timeout -k 10 500 python bench.py --corpus-gib 8 --steps 5 --warmup 1 > $out/bench_8gib_dist1.json 2> $out/bench_8gib_dist1.err

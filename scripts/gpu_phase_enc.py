@@ -16,10 +16,16 @@ for cls in [int(a) for a in sys.argv[1:]] or [5, 3, 1]:
     codec.compress_blocks(src, 65536); torch.cuda.synchronize()
     buf = (C.c_ulonglong * 16)()
     L.lz4mi_debug_enc_phases(buf, 1)
+    fx = (C.c_ulonglong * 16)()
+    if hasattr(L, 'lz4mi_debug_fast_exits'):
+        L.lz4mi_debug_fast_exits(fx, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); codec.compress_blocks(src, 65536); e1.record(); torch.cuda.synchronize()
     L.lz4mi_debug_enc_phases(buf, 1)
     v = list(buf)
+    if hasattr(L, 'lz4mi_debug_fast_exits'):
+        L.lz4mi_debug_fast_exits(fx, 1)
+        print('   short path exits per block (0 = done):', [round(x / NB, 1) for x in fx])
     print(f'class {cls}: {e0.elapsed_time(e1):.3f} ms for {NB} blocks', flush=True)
     for i, nm in enumerate(names):
         if i in (8, 9, 11, 12, 13):
