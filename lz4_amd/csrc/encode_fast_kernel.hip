@@ -177,6 +177,38 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v, uint32_t fill) {
   return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x110 + D, 0xF, 0xF, false);
 }
 
+// ---------------------------------------------------------------- table entries
+// Plain: generation (8 bits) | position + 1 (24 bits).  WIDE: position + 1.
+// TAG (blocks whose positions fit 17 bits: 64 KiB blocks, with or without a dictionary): generation | position + 1
+// (17 bits) | tag (7 bits), the tag being seven bits of the hashed sequence that the bucket index does not hold
+// (below the position, so that the larger entry of a bucket is still the larger position: inserts are maxima).
+// An entry whose tag differs from the probe's has other bytes at its position than the probe (the tag is a
+// function of the four bytes), so the reference's byte compare (:103) would fail: the candidate is dropped without
+// fetching those bytes.  Most candidates are such stale bucket-mates, and most of them lie behind the input ring,
+// where looking at them is a round trip to memory.
+constexpr uint32_t kHashMul = 2654435761u;  // :167-170: hash = (seq * kHashMul) >> 16
+constexpr uint32_t kTagPosBits = 17, kTagPosMask = (1u << kTagPosBits) - 1;
+__device__ __forceinline__ uint32_t tag_of(uint32_t prod) { return (prod >> 9) & 0x7Fu; }
+
+template <bool WIDE, bool TAG>
+__device__ __forceinline__ uint32_t entry_value(uint32_t gen, uint32_t prod, uint32_t pos) {
+  if (WIDE) return pos + 1;
+  if (TAG) return (gen << kPosBits) | ((pos + 1) << 7) | tag_of(prod);
+  return (gen << kPosBits) | (pos + 1);
+}
+// Position held by a table entry for a probe with hashed sequence `prod`, or -1.  own: the bucket holds a position
+// of this block (so a shared dictionary's table is not asked, whatever the tag says).
+template <bool WIDE, bool TAG>
+__device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen, uint32_t prod, bool &own) {
+  if (WIDE) {
+    own = e != 0;
+    return (int32_t)e - 1;
+  }
+  own = (e >> kPosBits) == gen;
+  if (TAG) return own && (e & 0x7Fu) == tag_of(prod) ? (int32_t)((e >> 7) & kTagPosMask) - 1 : -1;
+  return own ? (int32_t)(e & kPosMask) - 1 : -1;
+}
+
 // One re-hash step: table[hash] = position for up to 64 ascending positions.  Inserts go out as
 // plain stores (a store to a line that is not cached needs no fetch, an atomic does).  Positions
 // rise with the lane, so of the lanes of one instruction that share a bucket only the highest may
@@ -203,10 +235,12 @@ __device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_
     if (open) *slot2 = 0;
     open = open && (top & 0xFFFFu) != hj;
   }
+#ifndef LZ4MI_TIMING_NO_REHASH_STORES
   if (live) {
     if (open) tbl_max(T + hj, value);
     else if (top == mine) tbl_store(T + hj, value);
   }
+#endif
 }
 
 // smallest h ^ h(lane - k) over k = 1..K within a row of 16 lanes: zero iff an earlier lane holds the same value
@@ -292,8 +326,8 @@ __device__ __forceinline__ uint32_t write_sequences(const Win &w, const SeqBatch
 // Interior re-hash of a match (:135-145) that started at ms and ended at `anchor` (exclusive): of the positions
 // ms+1 .. anchor-4 only the last `dist` can survive in the table (position j and j + dist hash the same bytes and
 // j + dist is inserted later).
-template <bool HAS_DICT>
-__device__ __forceinline__ void rehash_match(const EncIn &in, const Win &w, uint32_t *T, lds_u32 *claim, uint32_t gtag,
+template <bool HAS_DICT, bool WIDE, bool TAG>
+__device__ __forceinline__ void rehash_match(const EncIn &in, const Win &w, uint32_t *T, lds_u32 *claim, uint32_t gen,
                                              uint32_t ms, uint32_t dist, uint32_t anchor, uint32_t lane) {
   const uint32_t D = HAS_DICT ? in.D : 0u;
   if (anchor + 4 <= in.plimit) {
@@ -303,12 +337,16 @@ __device__ __forceinline__ void rehash_match(const EncIn &in, const Win &w, uint
     if (anchor - D <= w.hi) {  // lo - D >= s >= w.lo
       for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
         const uint32_t j = j0 + lane;
-        insert_step(T, claim, hash16(w32(w, j - D)), gtag | (j + 1), j <= hi, lane);
+        const uint32_t prod = w32(w, j - D) * kHashMul;
+        insert_step(T, claim, prod >> 16, entry_value<WIDE, TAG>(gen, prod, j), j <= hi, lane);
       }
     } else {
       for (uint32_t j0 = lo; j0 <= hi; j0 += kWave) {
         const uint32_t j = j0 + lane;
-        if (j <= hi) tbl_max(T + hash16(rd32<HAS_DICT>(in, w, j)), gtag | (j + 1));
+        if (j <= hi) {
+          const uint32_t prod = rd32<HAS_DICT>(in, w, j) * kHashMul;
+          tbl_max(T + (prod >> 16), entry_value<WIDE, TAG>(gen, prod, j));
+        }
       }
       vm_quiesce();  // rare path: leave no load pending at the join
     }
@@ -329,17 +367,19 @@ __device__ __forceinline__ uint64_t m_ule(uint32_t a, uint32_t b) { return __bui
 // meet in a slot of the vote array (so no two share a bucket); one of them hits; the reference lies inside the
 // ring with the margins of the one-round-trip extension; the match is shorter than 32 bytes backwards and 256
 // forwards.  What it does is what the general code does (same reads, same table writes, same sequence).
-__device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t *T, lds_u32 *claim, uint32_t gen,
+enum { kSeqDone = 0, kSeqGeneral = 1 };
+template <bool TAG>
+__device__ __forceinline__ int fast_sequence(const EncIn &in, Win &w, uint32_t *T, lds_u32 *claim, uint32_t gen,
                                               uint32_t offP, uint32_t ext_off, uint32_t ext_need, uint32_t lane,
                                               uint32_t &anchor, SeqBatch &batch, uint32_t &nbatch, uint32_t &op,
-                                              uint8_t *out) {
+                                              uint8_t *out, PhState &ph) {
   const uint32_t n = in.total, plimit = in.plimit, elimit = in.elimit;
+  PHS(ph, 16);
   const uint32_t s = anchor;
-  const uint32_t gtag = gen << kPosBits;
   {
     const uint32_t need = s + kLead < n ? s + kLead : n;
-    if (s < w.lo || w.hi < need) { FAST_EXIT(1); return false; }
-    if (s + 128 > plimit) { FAST_EXIT(3); return false; }                      // the block's end (every probe below is a valid one)
+    if (s < w.lo || w.hi < need) { FAST_EXIT(1); return kSeqGeneral; }
+    if (s + 128 > plimit) { FAST_EXIT(3); return kSeqGeneral; }                      // the block's end (every probe below is a valid one)
   }
   // the next segment is requested together with the table gather and lands after the same wait
   const bool pend = w.hi < n && w.hi < s + kLead + kSeg;
@@ -348,8 +388,10 @@ __device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t 
   // Lanes behind the first kFirst repeat lane 0's probe (offP is zero there): same addresses, same answers.
   const uint32_t ik = s + offP;
   const uint32_t seq = w32(w, ik);
-  const uint32_t h = hash16(seq);
+  const uint32_t prod = seq * kHashMul;
+  const uint32_t h = prod >> 16;
   const uint32_t e = tbl_load(T + h);
+  PHS(ph, 17);
   // probes that meet in a byte slot of the vote array (all zero between uses) see each other's lane number
   uint32_t seen = lane + 1;
   if (lane < kFirst) {
@@ -358,10 +400,14 @@ __device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t 
     seen = *mark;
     *mark = 0;
   }
-  uint32_t ref = e - (gtag + 1);  // the entry's position when its generation is this block's
+#ifdef LZ4MI_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PHS(ph, 18);
+#endif
+  // the entry's position when its generation (and tag) are the probe's; :102 (such an entry lies in front of ik)
+  uint32_t ref = TAG ? ((e >> 7) & kTagPosMask) - 1 : e - ((gen << kPosBits) + 1);
   uint32_t distv = ik - ref;
-  // :102 (an entry of this block's generation lies in front of ik)
-  uint64_t cand = m_eq(e >> kPosBits, gen) & m_ule(distv, 0xFFFFu);
+  uint64_t cand = (TAG ? m_eq((e ^ tag_of(prod)) & 0xFF00007Fu, gen << kPosBits) : m_eq(e >> kPosBits, gen)) & m_ule(distv, 0xFFFFu);
   const uint64_t clash = m_ne(seen, lane + 1);
   if (clash) {
     // Probes that may share a bucket: an earlier probe of the run in the same bucket acts as the table entry
@@ -383,24 +429,41 @@ __device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t 
     distv = ik - ref;
   }
   cand &= (1ull << kFirst) - 1ull;  // the lanes behind the probes copy lane 0: no hit of theirs counts
+  if (cand == 0) {
+    if (pend) seg_store(w, w.hi, pv, lane);
+    vm_quiesce();
+    FAST_EXIT(4);
+    return kSeqGeneral;
+  }
   uint32_t rb = w32(w, ref);
   const uint64_t far = cand & m_ult(ref, w.lo);
+#ifndef LZ4MI_TIMING_NO_FAR
   if (far) {  // references the ring has dropped: their bytes come from memory
     if (__builtin_amdgcn_inverse_ballot_w64(far)) rb = ld32(in.src + ref);
   }
+#endif
   const uint64_t hit = cand & m_eq(rb, seq);  // :103
   if (pend) seg_store(w, w.hi, pv, lane);
   vm_quiesce();
-  if (hit == 0) { FAST_EXIT(4); return false; }
+  if (hit == 0) { FAST_EXIT(4); return kSeqGeneral; }  // the run goes on behind its first probes: the general code
 
+  PHS(ph, 19);
   // ---- match at lane K
   const uint32_t K = (uint32_t)__builtin_ctzll(hit);
   const uint32_t i = rdlane(ik, K), dist = rdlane(distv, K), r0 = i - dist;
   const uint32_t maxb = i - anchor < r0 ? i - anchor : r0;
-  if (!(r0 >= w.lo + 32 && (i + 272 <= w.hi || w.hi >= n))) { FAST_EXIT(5); return false; }
   // lanes 0-31 compare one byte each going backwards (:107-113), lanes 32-63 eight bytes each going forwards (:117-121)
   const uint32_t pp = i + ext_off;
-  const uint64_t x = w64(w, pp) ^ w64(w, pp - dist);
+  uint64_t x;
+  if (r0 >= w.lo + 32 && (i + 272 <= w.hi || w.hi >= n)) {
+    x = w64(w, pp) ^ w64(w, pp - dist);
+  } else if (r0 >= 32 && i + 272 <= elimit && i + 272 <= w.hi) {
+    x = w64(w, pp) ^ ld64(in.src + (pp - dist));  // the reference lies behind the ring: its side comes from memory
+    vm_quiesce();
+  } else {
+    FAST_EXIT(5);
+    return kSeqGeneral;
+  }
   const uint32_t e8 = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
   const uint32_t avail = pp < elimit ? elimit - pp : 0u;  // bytes past the match limit never count
   const uint32_t eq = e8 < avail ? e8 : avail;
@@ -409,12 +472,13 @@ __device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t 
   const uint32_t mb = maxb < 32 ? maxb : 32u;
   const uint64_t sm = m_ult(eq, ext_need) | (0xFFFFFFFFull & ~((1ull << mb) - 1ull));
   const uint32_t sm_lo = (uint32_t)sm, sm_hi = (uint32_t)(sm >> 32);
-  if (sm_lo == 0 || sm_hi == 0) { FAST_EXIT(6); return false; }  // longer than 32 backwards or 256 forwards
+  if (sm_lo == 0 || sm_hi == 0) { FAST_EXIT(6); return kSeqGeneral; }  // longer than 32 backwards or 256 forwards
   const uint32_t b = (uint32_t)__builtin_ctz(sm_lo);
   const uint32_t L = (uint32_t)__builtin_ctz(sm_hi);
   const uint32_t fwd = 8 * L + rdlane(eq, 32 + L);
   const uint32_t ms = i - b, ml = b + 4 + fwd, lit = ms - anchor;
 
+  PHS(ph, 20);
   // ---- nothing can fail from here on: _writeSequence (deferred), :100 for the probes up to the hit, :132-145
   put_seq(batch, s, lit, dist, ml, nbatch);
   if (++nbatch == kBatch) {
@@ -422,23 +486,24 @@ __device__ __forceinline__ bool fast_sequence(const EncIn &in, Win &w, uint32_t 
     nbatch = 0;
   }
   anchor = ms + ml;
+#ifndef LZ4MI_TIMING_NO_PROBE_INS
   if (lane <= K) {  // :100 for every probe of the step up to the hit; probes that may share a bucket take the maximum
-    if (clash) tbl_max(T + h, gtag | (ik + 1));
-    else tbl_store(T + h, gtag | (ik + 1));
+    const uint32_t v = entry_value<false, TAG>(gen, prod, ik);
+    if (clash) tbl_max(T + h, v);
+    else tbl_store(T + h, v);
   }
-  rehash_match<false>(in, w, T, claim, gtag, ms, dist, anchor, lane);
+#endif
+  PHS(ph, 21);
+#ifndef LZ4MI_TIMING_NO_REHASH
+  rehash_match<false, false, TAG>(in, w, T, claim, gen, ms, dist, anchor, lane);
+#endif
+  PHS(ph, 22);
   FAST_EXIT(0);
-  return true;
+  return kSeqDone;
 }
 
-// Position held by a table entry, or -1.
-template <bool WIDE>
-__device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen) {
-  if (WIDE) return (int32_t)e - 1;
-  return (e >> kPosBits) == gen ? (int32_t)(e & kPosMask) - 1 : -1;
-}
 
-template <bool HAS_DICT, bool LINKED, bool WIDE>
+template <bool HAS_DICT, bool LINKED, bool WIDE, bool TAG>
 __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *out, uint32_t cap, uint32_t sh,
                                                      uint32_t *T, const uint32_t *__restrict__ dictT,
                                                      uint32_t gen, uint32_t offA, uint32_t offB, lds_u8 *lds,
@@ -450,17 +515,22 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
   out_len = 0;
   if (n == 0) return LZ4MI_OK;  // :45-48
   if ((uint64_t)cap < (uint64_t)n + n / 255u + 16u) return LZ4MI_DST_TOO_SMALL;
-  if (total > (WIDE ? 0x7FFFFFF0u : kPosMask - 1)) return LZ4MI_UNSUPPORTED_HERE;  // position width of the table
-  const uint32_t gtag = WIDE ? 0u : gen << kPosBits;
+  if (total > (WIDE ? 0x7FFFFFF0u : TAG ? kTagPosMask : kPosMask - 1)) return LZ4MI_UNSUPPORTED_HERE;  // position width of the table
   uint32_t anchor = D, op = 0;
   PH_DECL
+#ifdef LZ4MI_PROFILE
+  PhState phs = {ph_c_, ph_t_};
+#else
+  PhState phs;
+#endif
 
   if (n >= 4) {  // :74-78
     if (LINKED && D >= 4) {  // :83-88, the block's own dictionary goes into its own table
       for (uint32_t j0 = 0; j0 + 4 <= D; j0 += kWave) {
         const uint32_t j = j0 + lane;
         const bool live = j + 4 <= D;
-        insert_step(T, claim, live ? hash16(ld32(in.dict + j)) : 0u, gtag | (j + 1), live, lane);
+        const uint32_t prod = live ? ld32(in.dict + j) * kHashMul : 0u;
+        insert_step(T, claim, prod >> 16, entry_value<WIDE, TAG>(gen, prod, j), live, lane);
       }
     }
     Win w = {lds, in.src, n, 0, 0};
@@ -473,8 +543,14 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
     while (anchor + 4 <= plimit) {  // one iteration per sequence
 #ifndef LZ4MI_NO_FAST_SEQ
       if (!HAS_DICT && !LINKED && !WIDE) {
-        if (fast_sequence(in, w, T, claim, gen, offP, ext_off, ext_need, lane, anchor, batch, nbatch, op, out)) continue;
+        if (fast_sequence<TAG>(in, w, T, claim, gen, offP, ext_off, ext_need, lane, anchor, batch, nbatch, op, out, phs) ==
+            kSeqDone)
+          continue;
       }
+#endif
+#ifdef LZ4MI_PROFILE
+      PHS(phs, 23);  // what a short-path attempt that gave up has cost
+      ph_t_ = phs.t;
 #endif
       const uint32_t s = anchor - D;
       {
@@ -491,7 +567,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       uint32_t ik = anchor + offA;
       bool valid = lane < kFirst && ik + 4 <= plimit;
       uint32_t seq = w32(w, ik - D);
-      uint32_t h = hash16(seq);
+      uint32_t prod = seq * kHashMul;
+      uint32_t h = prod >> 16;
       int32_t ref = -1;
       {
         // Every lane loads (idle lanes re-read bucket 0): a gather without a branch around it
@@ -499,8 +576,9 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         const uint32_t hx = valid ? h : 0u;
         const uint32_t e = tbl_load(T + hx);
         const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[hx] : 0u;
-        ref = entry_ref<WIDE>(e, gen);
-        if (HAS_DICT && !LINKED && ref < 0) ref = (int32_t)ed - 1;
+        bool own;
+        ref = entry_ref<WIDE, TAG>(e, gen, prod, own);
+        if (HAS_DICT && !LINKED && !own) ref = (int32_t)ed - 1;
       }
       uint32_t nvalid = (uint32_t)__builtin_popcountll(ballot(valid));  // >= 1, valid lanes form a prefix
 #ifdef LZ4MI_PROFILE
@@ -558,8 +636,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
       // ---- the rest of the run, 64 probes at a time
       if (!hm && nvalid == kFirst) {
         if (valid) {  // :100, all of them missed
-          if (dup) tbl_max(T + h, gtag | (ik + 1));
-          else tbl_store(T + h, gtag | (ik + 1));
+          if (dup) tbl_max(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
+          else tbl_store(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
         }
         valid = false;
         uint32_t o_last = 0;
@@ -575,14 +653,16 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           nvalid = (uint32_t)__builtin_popcountll(ballot(valid));
           if (nvalid == 0) break;
           PH_CNT(8);
-          seq = 0; h = 0; ref = -1;
+          seq = 0; prod = 0; h = 0; ref = -1;
           if (valid) {
             seq = rd32<HAS_DICT>(in, w, ik);
-            h = hash16(seq);
+            prod = seq * kHashMul;
+            h = prod >> 16;
             const uint32_t e = tbl_load(T + h);
             const uint32_t ed = (HAS_DICT && !LINKED) ? dictT[h] : 0u;
-            ref = entry_ref<WIDE>(e, gen);
-            if (HAS_DICT && !LINKED && ref < 0) ref = (int32_t)ed - 1;
+            bool own;
+            ref = entry_ref<WIDE, TAG>(e, gen, prod, own);
+            if (HAS_DICT && !LINKED && !own) ref = (int32_t)ed - 1;
           }
           {  // same-bucket probes of this chunk, nearest earlier lane: 16 bit-plane votes
             uint64_t peers = valid ? ((1ull << lane) - 1ull) : 0ull;
@@ -602,8 +682,8 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
           K = hm ? (uint32_t)__builtin_ctzll(hm) : nvalid - 1;
           if (hm) break;  // the probes up to the hit are inserted once the match is known
           if (valid) {
-            if (dup) tbl_max(T + h, gtag | (ik + 1));
-            else tbl_store(T + h, gtag | (ik + 1));
+            if (dup) tbl_max(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
+            else tbl_store(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
           }
           valid = false;
           if (nvalid < kWave) break;
@@ -712,13 +792,13 @@ __device__ __forceinline__ int32_t encode_block_fast(const EncIn in, uint8_t *ou
         // Every insert is at a larger position than the bucket held, and a wavefront's stores to one
         // address land in issue order, so a plain store does as long as no two lanes of THIS
         // instruction share a bucket.
-        if (dup) tbl_max(T + h, gtag | (ik + 1));
-        else tbl_store(T + h, gtag | (ik + 1));
+        if (dup) tbl_max(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
+        else tbl_store(T + h, entry_value<WIDE, TAG>(gen, prod, ik));
       }
       PH(6);
 
       // ---- :135-145 interior re-hash, last `dist` positions only
-      rehash_match<HAS_DICT>(in, w, T, claim, gtag, ms, dist, anchor, lane);
+      rehash_match<HAS_DICT, WIDE, TAG>(in, w, T, claim, gen, ms, dist, anchor, lane);
       PH(7);
     }
     if (nbatch) op = write_sequences(w, batch, nbatch, out, op, lane);
@@ -744,7 +824,7 @@ struct EncodeKArgs {
 };
 typedef const volatile __attribute__((address_space(4))) EncodeKArgs *EncodeKArgsPtr;
 
-template <bool HAS_DICT, bool LINKED, bool WIDE = false>
+template <bool HAS_DICT, bool LINKED, bool WIDE = false, bool TAG = false>
 __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[4][kClaimSlots];
@@ -811,7 +891,7 @@ __global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, E
 #ifdef LZ4MI_ENC_SPANS
     if (lane == 0 && b < 65536) g_enc_span[2 * b] = __builtin_amdgcn_s_memrealtime();
 #endif
-    int32_t st = encode_block_fast<HAS_DICT, LINKED, WIDE>(in, out, cap, sh, T, dictT, gen, offA, offB,
+    int32_t st = encode_block_fast<HAS_DICT, LINKED, WIDE, TAG>(in, out, cap, sh, T, dictT, gen, offA, offB,
                                                      (lds_u8 *)s_win[wave], (lds_u32 *)s_claim[wave], lane, out_len);
 #ifdef LZ4MI_ENC_SPANS
     if (lane == 0 && b < 65536) g_enc_span[2 * b + 1] = __builtin_amdgcn_s_memrealtime();
@@ -868,7 +948,15 @@ void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeSc
                         uint32_t grid, hipStream_t s) {
   // blocks whose positions need more than 24 bits (only with uniform lengths: one large block per call)
   const bool wide = !a.src_len && !a.linked && (uint64_t)a.src_len_uniform + a.dict_len > kPosMask - 2;
-  if (wide && a.dict_len)
+  // every position of every block fits the tagged entry's 17 bits (uniform block length known here)
+  const bool tag = !a.src_len && (uint64_t)a.src_len_uniform + (a.linked ? 65535u : a.dict_len) <= kTagPosMask;
+  if (tag && a.linked)
+    hipLaunchKernelGGL((encode_fast_kernel<true, true, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (tag && a.dict_len)
+    hipLaunchKernelGGL((encode_fast_kernel<true, false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (tag)
+    hipLaunchKernelGGL((encode_fast_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+  else if (wide && a.dict_len)
     hipLaunchKernelGGL((encode_fast_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
   else if (wide)
     hipLaunchKernelGGL((encode_fast_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);

@@ -4,7 +4,7 @@
 // end of a block.  No output depends on the stamps.
 #pragma once
 #ifdef LZ4MI_PROFILE
-#define PH_SLOTS 16
+#define PH_SLOTS 32
 namespace lz4mi {
 __device__ __forceinline__ __attribute__((address_space(3))) uint32_t *ph_column() {
   __shared__ uint32_t slots[4 * PH_SLOTS * 64];
@@ -12,6 +12,17 @@ __device__ __forceinline__ __attribute__((address_space(3))) uint32_t *ph_column
   return (__attribute__((address_space(3))) uint32_t *)slots + wave * PH_SLOTS * 64 + (threadIdx.x & 63);
 }
 }  // namespace lz4mi
+// the stamps' state as one object, for code outside the function that declared it
+struct PhState {
+  __attribute__((address_space(3))) uint32_t *c;
+  unsigned long long t;
+};
+#define PHS(st, i)                                               \
+  do {                                                           \
+    unsigned long long n_ = __builtin_readcyclecounter();        \
+    (st).c[(i) * 64] += (uint32_t)(n_ - (st).t);                 \
+    (st).t = n_;                                                 \
+  } while (0)
 #define PH_DECL                                                              \
   __attribute__((address_space(3))) uint32_t *ph_c_ = lz4mi::ph_column();    \
   for (int q_ = 0; q_ < PH_SLOTS; q_++) ph_c_[q_ * 64] = 0;                  \
@@ -36,4 +47,6 @@ __device__ __forceinline__ __attribute__((address_space(3))) uint32_t *ph_column
 #define PH(i) do {} while (0)
 #define PH_CNT(i) do {} while (0)
 #define PH_FLUSH(arr, lane) do {} while (0)
+#define PHS(st, i) do {} while (0)
+struct PhState {};
 #endif

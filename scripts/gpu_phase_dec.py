@@ -19,7 +19,7 @@ for arg in sys.argv[1:] or ['5']:
     src = torch.from_numpy(np.concatenate([blocks[k % len(blocks)] for k in range(NB)])).cuda()
     slots, sizes, st = codec.compress_blocks(src, 65536, **({'hc_depth': int(HC)} if HC else {}))  # HC=<depth>: the HC encoder's output (short sequences)
     codec.decompress_blocks(slots, sizes, 65536); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 64)()
     L.lz4mi_debug_dec_phases(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); codec.decompress_blocks(slots, sizes, 65536); e1.record(); torch.cuda.synchronize()

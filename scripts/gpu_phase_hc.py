@@ -12,7 +12,7 @@ for cls in [int(a) for a in sys.argv[1:]] or [0, 3, 5]:
     blocks = [corpus_block(cls + 8 * k) for k in range(32)]
     src = torch.from_numpy(np.concatenate([blocks[k % 32] for k in range(NB)])).cuda()
     codec.compress_blocks(src, 65536, hc_depth=64); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 64)()
     L.lz4mi_debug_hc_phases(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); codec.compress_blocks(src, 65536, hc_depth=64); e1.record(); torch.cuda.synchronize()
