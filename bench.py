@@ -227,7 +227,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # LZ4MI_BENCH_DIST=1 takes the multi-rank code path (RCCL init, size exchange, frame assembly) with one
     # rank, to rehearse it on a one-GPU box
-    multi = world > 1 or os.environ.get("LZ4MI_BENCH_DIST") == "1" or args.config == 3
+    multi = world > 1 or os.environ.get("LZ4MI_BENCH_DIST") == "1" or args.config == 3 or args.corpus_gib > 0
     # LZ4MI_BENCH_ONE_GPU=1 puts every rank on GPU 0 and exchanges through gloo (RCCL takes one rank per device):
     # a rehearsal of the rank > 0 code path on a one-GPU box, not a measurement
     one_gpu = os.environ.get("LZ4MI_BENCH_ONE_GPU") == "1"
@@ -289,45 +289,65 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    phases = ("shard_compress", "size_exchange", "shard_write", "shard_decode", "decoded_size_exchange") if multi \
+    phases = ("shard_compress", "shard_write", "size_exchange", "shard_decode", "decoded_size_exchange") if multi \
         else ("encode_fast_kernel", "decode_kernel")
-    ev = {k: [] for k in phases}
+    ev = {k: [] for k in phases}  # per phase: one list of event pairs per timed step
     keep = {}
+    # A rank's shard goes through the encoder in sub-launches of at most this many blocks (8 GiB), so that the
+    # library's scratch for compressed payloads stays bounded whatever the shard size (64 GiB on one GPU included).
+    # A rank's window of the frame needs only the rank's own record sizes (offsets relative to its first record):
+    # it is written sub-launch by sub-launch; the all-gather of the sizes places the windows in the frame.
+    SUB = 131072
+    rec_all = torch.empty(nb, dtype=torch.int32, device=dev) if multi else None
+    rel_all = torch.empty(nb, dtype=torch.int64, device=dev) if multi else None
 
     def step(record):
         with torch.cuda.stream(stream):
-            marks = []
+            pairs = {k: [] for k in phases}
+            last = [None]
 
-            def mark():
-                if record:
-                    e = torch.cuda.Event(enable_timing=True)
-                    e.record(stream)
-                    marks.append(e)
+            def mark(phase=None):
+                if not record:
+                    return
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                if phase is not None:
+                    pairs[phase].append((last[0], e))
+                last[0] = e
             mark()
             if not multi:
                 _, sizes, st_c = codec.compress_blocks(src, BLOCK, acceleration=args.acceleration, out=slots)
-                mark()
+                mark("encode_fast_kernel")
                 _, out_len, st_d = codec.decompress_blocks(slots, sizes, BLOCK, comp_stride=stride, strict=True, out=out)
-                mark()
+                mark("decode_kernel")
                 keep.update(sizes=sizes, st_c=st_c, st_d=st_d, out_len=out_len)
             else:
-                rec = codec.shard_compress(src, opts)          # compress + record plan (device)
-                mark()
-                mine, body_end = frame_offsets_uniform(rec, len(header))  # RCCL all-gather + prefix sum
-                rel = (mine - mine[0]).contiguous()
-                mark()
-                codec.shard_write(src, opts, rel, window)      # records into this rank's window of the frame
-                mark()
-                _, out_len, st_d = codec.shard_decode(window, rel, opts, out=out)
-                mark()
+                base = torch.zeros(1, dtype=torch.int64, device=dev)  # where the next sub-launch's records start
+                for lo in range(0, nb, SUB):
+                    hi = min(nb, lo + SUB)
+                    part = src[lo * BLOCK:hi * BLOCK]
+                    rec = codec.shard_compress(part, opts)     # compress + record plan (device)
+                    mark("shard_compress")
+                    r64 = rec.to(torch.int64)
+                    ends = torch.cumsum(r64, 0) + base
+                    rel = ends - r64                           # offsets in this rank's window of the frame
+                    rec_all[lo:hi] = rec
+                    rel_all[lo:hi] = rel
+                    codec.shard_write(part, opts, rel, window)  # records into the window
+                    base = ends[-1:]
+                    mark("shard_write")
+                mine, body_end = frame_offsets_uniform(rec_all, len(header))  # RCCL all-gather + prefix sum
+                mark("size_exchange")
+                _, out_len, st_d = codec.shard_decode(window, rel_all, opts, out=out)
+                mark("shard_decode")
                 doff, total = decoded_offsets(out_len, uniform=True)  # the format allows short blocks
                 if not bool((out_len == BLOCK).all()):         # none here: blocks already sit at b * 64 KiB
                     raise AssertionError("short block in the bench corpus")
-                mark()
-                keep.update(rec=rec, mine=mine, body_end=body_end, rel=rel, out_len=out_len, st_d=st_d, total=total)
+                mark("decoded_size_exchange")
+                keep.update(rec=rec_all, mine=mine, body_end=body_end, rel=rel_all, out_len=out_len, st_d=st_d, total=total)
             if record:
-                for k, (a, b) in zip(phases, zip(marks, marks[1:])):
-                    ev[k].append((a, b))
+                for k in phases:
+                    ev[k].append(pairs[k])
 
     for _ in range(args.warmup):
         step(False)
@@ -347,7 +367,9 @@ def main():
     # ---- correctness of what was timed (outside the timed region)
     codec.fence = True  # from here on the codec's stream is ordered against torch's
     assert int(keep["st_d"].abs().sum()) == 0, "block status != OK"
-    assert torch.equal(out.reshape(-1), src), "decode(encode(x)) != x"
+    flat = out.reshape(-1)
+    for lo in range(0, src.numel(), 1 << 30):  # piecewise: a whole-shard compare would allocate a shard of booleans
+        assert torch.equal(flat[lo:lo + (1 << 30)], src[lo:lo + (1 << 30)]), "decode(encode(x)) != x"
     extra = {}
     if not multi:
         assert int(keep["st_c"].abs().sum()) == 0
@@ -364,6 +386,7 @@ def main():
         dist.all_gather_into_tensor(allrec, rec)
         starts = torch.cumsum(allrec, 0) - allrec + len(header)
         assert torch.equal(starts[rank * nb:(rank + 1) * nb], keep["mine"]), "record offsets != prefix sums"
+        assert torch.equal(keep["mine"] - keep["mine"][0], keep["rel"]), "window offsets != the rank's own prefix sums"
         assert int(keep["body_end"]) == int(starts[-1] + allrec[-1])
         assert int(keep["total"]) == world * nb * BLOCK
         extra["ranks_seen_by_rccl"] = dist.get_world_size()
@@ -380,7 +403,7 @@ def main():
             extra["window_checked_against_oracle_blocks"] = chk
 
     if rank == 0:
-        ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+        ms = {k: float(np.mean([sum(a.elapsed_time(b) for a, b in pairs) for pairs in v])) for k, v in ev.items()}
         n_bytes = nb * BLOCK
         gb = n_bytes / 1e9
         algo = (n_bytes + total_c) / 1e9  # algorithmic bytes of one launch: read n write c / read c write n
@@ -426,6 +449,9 @@ def main():
             "compress_GBps_per_gpu": gb / (ms[enc_k] / 1e3),
             "decompress_GBps_per_gpu": gb / (ms[dec_k] / 1e3),
             "phase_ms": ms,
+            "peak_device_bytes": {"torch_allocator": int(torch.cuda.max_memory_allocated(dev)),
+                                  "library_scratch": int(codec.L.lz4mi_ctx_device_bytes(codec.ctx.handle)),
+                                  "sub_launch_blocks": SUB if multi else nb},
             "roofline": {
                 "kernel": dom_kernel, "bound": "hbm", "achieved": roof[dom]["achieved"], "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": roof[dom]["frac"], "traffic": traffic_of(dom_kernel, nb, dom),
