@@ -182,6 +182,44 @@ def load_corpus(dev, first_block, nblocks):
     return src, host0
 
 
+CLASS_NAMES = ("random", "period-32 ramp", "byte run", "text-like", "text-like", "LZ-synthetic", "LZ-synthetic",
+               "random/text splice")
+
+
+def by_class(codec, src, nb, stride, acceleration):
+    """The two kernels on each corpus class by itself (block index mod 8), one launch of that class's blocks: the
+    headline launch mixes literal-only blocks, which are plain copies, with match-rich ones, and its fraction of the
+    roofline says little about either.  Not part of the timed region."""
+    out = {}
+    blocks = src.view(nb, BLOCK)
+    for cls in range(8):
+        part = blocks[cls::8].contiguous().reshape(-1)
+        n = part.numel() // BLOCK
+        if n == 0:
+            continue
+        slots = dec = None
+        best = [1e9, 1e9]
+        with torch.cuda.stream(codec.stream):
+            for _ in range(3):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                e[0].record(codec.stream)
+                slots, sizes, st_c = codec.compress_blocks(part, BLOCK, acceleration=acceleration, out=slots)
+                e[1].record(codec.stream)
+                dec, out_len, st_d = codec.decompress_blocks(slots, sizes, BLOCK, comp_stride=stride, strict=True, out=dec)
+                e[2].record(codec.stream)
+                codec.synchronize()
+                best = [min(best[0], e[0].elapsed_time(e[1])), min(best[1], e[1].elapsed_time(e[2]))]
+        assert int(st_c.abs().sum()) == 0 and int(st_d.abs().sum()) == 0 and torch.equal(dec.reshape(-1), part)
+        c = int(sizes.to(torch.int64).sum())
+        algo = (part.numel() + c) / 1e9
+        out[f"{cls} {CLASS_NAMES[cls]}"] = {
+            "blocks": n, "ratio": c / part.numel(),
+            "encode_ms": best[0], "decode_ms": best[1],
+            "encode_frac": algo / (best[0] / 1e3) / HBM_PEAK_GBPS, "decode_frac": algo / (best[1] / 1e3) / HBM_PEAK_GBPS,
+        }
+    return out
+
+
 def traffic_of(kernel, blocks_per_launch, phase):
     """HBM bytes per launch from the PMC passes, or None when they profiled another launch shape than this run's
     (another number of blocks per launch, or the sharded step's window kernels)."""
@@ -461,6 +499,8 @@ def main():
             "roofline_all": roof,
             "reference_published": REFERENCE_PUBLISHED,
         }
+        if not multi:
+            result["roofline_by_class"] = by_class(codec, src, nb, stride, args.acceleration)
         if world == 1 and not multi and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)
             cb = cpu_baseline(data0, threads)

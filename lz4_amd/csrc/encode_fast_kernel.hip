@@ -373,6 +373,9 @@ __device__ __forceinline__ int fast_sequence(const EncIn &in, Win &w, uint32_t *
                                               uint32_t offP, uint32_t ext_off, uint32_t ext_need, uint32_t lane,
                                               uint32_t &anchor, SeqBatch &batch, uint32_t &nbatch, uint32_t &op,
                                               uint8_t *out, PhState &ph) {
+  // the margin of 128 bytes in front of the last searched position covers the probes' reach (offset 61 + 4 bytes with
+  // acceleration 1, less with more) and the row shifts below cover nine earlier probes
+  static_assert(kFirst <= 10, "the short path is written for at most ten probes in the first step");
   const uint32_t n = in.total, plimit = in.plimit, elimit = in.elimit;
   PHS(ph, 16);
   const uint32_t s = anchor;

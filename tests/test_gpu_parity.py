@@ -473,6 +473,45 @@ def test_encoder_structured_fuzz_vs_oracle(codec, oracle):
             assert np.array_equal(got, data)
 
 
+def test_encoder_entry_formats_and_short_periods_vs_oracle(codec, oracle):
+    """Both table entry formats at the sizes where they change (positions of 17 bits carry a tag of the hashed
+    sequence: block + dictionary up to 131 071 bytes), with data that repeats at short distances all over (several
+    probes of one run in the same bucket) and with copies from all distances; bytes identical to the oracle."""
+    import torch
+    rng = np.random.default_rng(4711)
+
+    def periodic(n):
+        out = np.empty(n, dtype=np.uint8)
+        p = 0
+        while p < n:
+            k = int(rng.choice([1, 2, 3, 5, 8, 13, 30, 61, 64, 100]))
+            ln = min(n - p, int(rng.integers(8, 400)))
+            unit = rng.integers(0, 256, size=k, dtype=np.uint8)
+            out[p:p + ln] = np.resize(unit, ln)
+            p += ln
+            lit = min(n - p, int(rng.integers(0, 90)))
+            out[p:p + lit] = rng.integers(0, 256, size=lit, dtype=np.uint8)
+            p += lit
+        return out
+
+    dict_np = periodic(65535)
+    for block, nb, accel, dlen in ((131071, 6, 1, 0), (131072, 6, 1, 0), (65536, 12, 1, 65535), (65537, 6, 2, 65535),
+                                   (65536, 24, 1, 0), (65536, 12, 3, 0), (50000, 12, 9, 30000)):
+        data = np.concatenate([periodic(block) if b % 2 else _structured(rng, block) for b in range(nb)])
+        src = torch.tensor(data, device="cuda")
+        d_np = dict_np[:dlen] if dlen else None
+        d_t = torch.tensor(d_np, device="cuda") if dlen else None
+        slots, sizes, status = codec.compress_blocks(src, block, acceleration=accel, dictionary=d_t)
+        assert int(status.abs().sum()) == 0
+        h_slots, h_sizes = slots.cpu().numpy(), sizes.cpu().numpy()
+        for b in range(nb):
+            ref = oracle.block_compress_fast(data[b * block:(b + 1) * block].tobytes(), acceleration=accel,
+                                             dictionary=d_np.tobytes() if dlen else None)
+            assert int(h_sizes[b]) == len(ref) and h_slots[b, : len(ref)].tobytes() == ref, (block, b, accel, dlen)
+        out, out_len, st = codec.decompress_blocks(slots, sizes, block, strict=False, dictionary=d_t)
+        assert int(st.abs().sum()) == 0 and torch.equal(out.reshape(-1)[: data.size], src)
+
+
 def test_encoder_sequence_shapes_vs_oracle(codec, oracle):
     """Inputs built as (random literal run, copy of earlier bytes) pairs whose lengths sit on the
     boundaries of the sequence format (_writeSequence / _writeLength, lib/src/block/lz4_block_encoder.dart:172-223):
