@@ -167,7 +167,7 @@ static std::vector<DevBuf *> ctx_buffers(lz4mi_ctx *c) {
   return {&c->tables, &c->slot_gen, &c->dict_table, &c->dict_copy, &c->in, &c->out, &c->aux,
           &c->dictbuf, &c->comp, &c->comp_len, &c->status, &c->stored_word, &c->payload_addr,
           &c->payload_len, &c->record_size, &c->rec_off, &c->hashes, &c->words, &c->total,
-          &c->hc_chain, &c->hc_floor, &c->order};
+          &c->hc_chain, &c->hc_floor, &c->order, &c->link};
 }
 
 extern "C" uint64_t lz4mi_ctx_device_bytes(lz4mi_ctx *c) {

@@ -64,6 +64,8 @@ struct lz4mi_ctx {
   lz4mi::DevBuf hc_chain, hc_floor;
   // decoder: queue position -> block index of a launch (long blocks first)
   lz4mi::DevBuf order;
+  // linked frames: block offsets, the distance array of a chunk, its tile flags
+  lz4mi::DevBuf link;
 
   // state kept between lz4mi_frame_shard_compress and lz4mi_frame_shard_write
   uint32_t shard_blocks = 0;

@@ -395,6 +395,105 @@ static size_t decode_scratch_budget() {
   return mb << 20;
 }
 
+// A linked frame of at least this many blocks is decoded all blocks at once (fewer: the chain's one launch is
+// quicker than the fixed cost of the passes).
+constexpr uint32_t kLinkMinBlocks = 4;
+constexpr uint64_t kLinkChunkBytes = 256u << 20;  // output bytes resolved together (four bytes of scratch each)
+
+// LZ4MI_LINK_RESOLVE=0 keeps every linked frame on the chain (for comparisons).
+static bool link_resolve_enabled() {
+  const char *v = getenv("LZ4MI_LINK_RESOLVE");  // read per call: tests switch it between two decodes
+  return !(v && v[0] == '0');
+}
+
+// Sizes of all blocks (h_olen, h_stat), then chunk by chunk: literals and distances, doubling rounds until no
+// distance moves, the copied bytes.  *resolved = false when a block is not for this path (the output buffer may
+// hold partial data then; the chain writes all of it again).
+static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_t *d_dict, uint32_t *h_olen,
+                            int32_t *h_stat, bool *resolved) {
+  *resolved = false;
+  const uint64_t slot = la.block_max;
+  la.first = 0;
+  la.nblocks = nb;
+  launch_link_walk(la, false, c->stream);
+  LZ4MI_HIP(c, hipGetLastError());
+  LZ4MI_HIP(c, hipMemcpyAsync(h_olen, la.out_len, (size_t)nb * 12, hipMemcpyDeviceToHost, c->stream));  // sizes, statuses, block hashes
+  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  uint64_t total = 0;
+  for (uint32_t b = 0; b < nb; b++) {
+    if (h_stat[b] != 0 || h_olen[b] > slot) return LZ4MI_OK;
+    total += h_olen[b];
+  }
+  // scratch: block offsets, tile flags and the moved word, the distance array of the largest chunk
+  uint64_t chunk_cap = 0, run = 0;
+  for (uint32_t b = 0; b < nb; b++) {  // chunks as the loop below cuts them
+    if (run && run + h_olen[b] > kLinkChunkBytes) {
+      chunk_cap = run > chunk_cap ? run : chunk_cap;
+      run = 0;
+    }
+    run += h_olen[b];
+  }
+  chunk_cap = run > chunk_cap ? run : chunk_cap;
+  const size_t starts_bytes = round_up((size_t)nb * 8, 256);
+  const size_t flag_bytes = round_up((size_t)link_tiles(chunk_cap) + 16, 256);
+  const size_t dist_bytes = (size_t)link_dist_words(chunk_cap) * 4;
+  LZ4MI_HIP(c, c->link.ensure(starts_bytes + flag_bytes + dist_bytes));
+  LZ4MI_HIP(c, c->out.ensure((size_t)total + 16));
+  uint64_t *d_start = c->link.as<uint64_t>();
+  uint8_t *d_flags = c->link.as<uint8_t>() + starts_bytes;  // [moved u32][pad][one byte per tile]
+  uint32_t *d_moved = (uint32_t *)d_flags;
+  uint8_t *d_done = d_flags + 16;
+  uint32_t *d_dist = (uint32_t *)(c->link.as<uint8_t>() + starts_bytes + flag_bytes);
+  std::vector<uint64_t> starts(nb);
+  uint64_t at = 0;
+  for (uint32_t b = 0; b < nb; b++) {
+    starts[b] = at;
+    at += h_olen[b];
+  }
+  LZ4MI_HIP(c, hipMemcpyAsync(d_start, starts.data(), (size_t)nb * 8, hipMemcpyHostToDevice, c->stream));
+  la.dst = c->out.as<uint8_t>();
+  la.start = d_start;
+  la.dist = d_dist;
+  uint32_t *h_word = (uint32_t *)c->h_pin + (c->h_pin_cap / 4 - 1);  // last word of the pinned scratch
+  uint32_t b0 = 0;
+  while (b0 < nb) {
+    uint32_t b1 = b0;
+    uint64_t n = 0;
+    while (b1 < nb && (b1 == b0 || n + h_olen[b1] <= kLinkChunkBytes)) n += h_olen[b1++];
+    la.first = b0;
+    la.nblocks = b1 - b0;
+    la.chunk_start = starts[b0];
+    if (n) {
+      LZ4MI_HIP(c, hipMemsetAsync(d_dist, 0, (size_t)link_dist_words(n) * 4, c->stream));
+      LZ4MI_HIP(c, hipMemsetAsync(d_flags, 0, (size_t)link_tiles(n) + 16, c->stream));
+      launch_link_walk(la, true, c->stream);
+      LZ4MI_HIP(c, hipGetLastError());
+      // the second walk checks the distances against the block's place in the frame
+      LZ4MI_HIP(c, hipMemcpyAsync(h_stat + b0, la.status + b0, (size_t)(b1 - b0) * 4, hipMemcpyDeviceToHost, c->stream));
+      bool first_round = true;
+      for (;;) {
+        LZ4MI_HIP(c, hipMemsetAsync(d_moved, 0, 4, c->stream));
+        launch_link_jump(d_dist, n, d_done, d_moved, c->stream);
+        launch_link_jump(d_dist, n, d_done, d_moved, c->stream);
+        LZ4MI_HIP(c, hipGetLastError());
+        LZ4MI_HIP(c, hipMemcpyAsync(h_word, d_moved, 4, hipMemcpyDeviceToHost, c->stream));
+        LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+        if (first_round) {
+          for (uint32_t b = b0; b < b1; b++)
+            if (h_stat[b] != 0) return LZ4MI_OK;
+          first_round = false;
+        }
+        if (!*h_word) break;
+      }
+      launch_link_gather(d_dist, n, c->out.as<uint8_t>(), la.chunk_start, d_dict, la.dict_len, c->stream);
+      LZ4MI_HIP(c, hipGetLastError());
+    }
+    b0 = b1;
+  }
+  *resolved = true;
+  return LZ4MI_OK;
+}
+
 // Decodes the collected blocks on the device and folds the per-block results in stream
 // order.  `region` = host bytes that contain every payload, uploaded once.
 // walk_err: structural error met while reading block blocks.size() (0 = none).
@@ -517,7 +616,32 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     return true;
   };
 
-  if (!indep) {
+  bool resolved = false;
+  if (!indep && nb >= kLinkMinBlocks && (uint64_t)nb * slot <= limit_total + slot && link_resolve_enabled()) {
+    // linked blocks, every block at once (decode_linked_kernel.hip); anything but a well-formed frame that fits
+    // the limits is left to the chain below
+    LinkArgs la;
+    memset(&la, 0, sizeof la);
+    la.src = c->in.as<uint8_t>();
+    la.payload_off = d_poff;
+    la.payload_len = d_plen;
+    la.raw = d_raw;
+    la.block_max = (uint32_t)slot;
+    la.dict_len = (uint32_t)(d_dict ? dict_len : 0);
+    la.out_len = d_olen;
+    la.status = d_stat;
+    st = link_resolve(c, la, nb, d_dict, h_olen, h_stat, &resolved);
+    if (st) return st;
+    if (resolved) {
+      for (uint32_t b = 0; b < nb; b++)
+        if (!fold(b)) break;
+      d_frame_out = c->out.as<uint8_t>();
+    } else {
+      LZ4MI_HIP(c, hipMemsetAsync(d_olen, 0, (size_t)nb * 8, c->stream));
+    }
+  }
+  if (resolved) {
+  } else if (!indep) {
     // linked blocks: one wavefront walks the chain over one contiguous output
     LZ4MI_HIP(c, c->out.ensure((size_t)final_cap + 16));
     ChainArgs ch;

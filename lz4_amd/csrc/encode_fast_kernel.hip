@@ -209,6 +209,13 @@ __device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen, uint32_t 
   return own ? (int32_t)(e & kPosMask) - 1 : -1;
 }
 
+// Lane masks straight from a compare (a ballot of a bool costs a select and a second compare on the way).
+__device__ __forceinline__ uint64_t m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ __forceinline__ uint64_t m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ __forceinline__ uint64_t m_uge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
+__device__ __forceinline__ uint64_t m_ult(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
+__device__ __forceinline__ uint64_t m_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
+
 // One re-hash step: table[hash] = position for up to 64 ascending positions.  Inserts go out as
 // plain stores (a store to a line that is not cached needs no fetch, an atomic does).  Positions
 // rise with the lane, so of the lanes of one instruction that share a bucket only the highest may
@@ -219,27 +226,31 @@ __device__ __forceinline__ int32_t entry_ref(uint32_t e, uint32_t gen, uint32_t 
 __device__ __forceinline__ void insert_step(uint32_t *T, lds_u32 *claim, uint32_t hj, uint32_t value, bool live,
                                             uint32_t lane) {
   const uint32_t mine = ((lane + 1) << 16) | hj;
-  lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
-  if (live) (void)__hip_atomic_fetch_max(slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-  uint32_t top = live ? *slot : mine;
-  if (live) *slot = 0;
-  bool open = live && (top & 0xFFFFu) != hj;
-  if (ballot(open)) {
+  uint32_t top = mine;  // a lane without a position never stores: `live` is asked again at the store
+  if (live) {
+    volatile lds_u32 *slot = claim + (hj & (kClaimSlots - 1));
+    (void)__hip_atomic_fetch_max((lds_u32 *)slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    top = *slot;
+    *slot = 0;
+  }
+  bool open = (top & 0xFFFFu) != hj;
+  if (m_ne(top & 0xFFFFu, hj)) {
     // Lanes that met another bucket in their slot vote again among themselves, on the other half of
     // the hash (lanes of one bucket share their fate in every round, so the vote stays complete).
     // An atomic in front of the next table gather costs that gather the atomic's whole round trip,
     // which under load is several times the gather's own; a second LDS round trip is cheap next to it.
-    lds_u32 *slot2 = claim + ((hj >> 8) & (kClaimSlots - 1));
-    if (open) (void)__hip_atomic_fetch_max(slot2, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (open) top = *slot2;
-    if (open) *slot2 = 0;
-    open = open && (top & 0xFFFFu) != hj;
+    if (open) {
+      volatile lds_u32 *slot2 = claim + ((hj >> 8) & (kClaimSlots - 1));
+      (void)__hip_atomic_fetch_max((lds_u32 *)slot2, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      top = *slot2;
+      *slot2 = 0;
+    }
+    open = (top & 0xFFFFu) != hj;
   }
 #ifndef LZ4MI_TIMING_NO_REHASH_STORES
-  if (live) {
-    if (open) tbl_max(T + hj, value);
-    else if (top == mine) tbl_store(T + hj, value);
-  }
+  uint32_t *p = T + hj;
+  if (open) tbl_max(p, value);
+  if (top == mine && live) tbl_store(p, value);
 #endif
 }
 
@@ -352,13 +363,6 @@ __device__ __forceinline__ void rehash_match(const EncIn &in, const Win &w, uint
     }
   }
 }
-
-// Lane masks straight from a compare (a ballot of a bool costs a select and a second compare on the way).
-__device__ __forceinline__ uint64_t m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
-__device__ __forceinline__ uint64_t m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
-__device__ __forceinline__ uint64_t m_uge(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 35); }
-__device__ __forceinline__ uint64_t m_ult(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 36); }
-__device__ __forceinline__ uint64_t m_ule(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 37); }
 
 // One sequence the short way, for blocks without a dictionary: every assumption of the common case is checked
 // on the way and nothing is written before the last of them holds, so a `false` leaves the state as it was and

@@ -71,6 +71,31 @@ struct ChainArgs {
 };
 
 void launch_decode_chain(const ChainArgs &c, hipStream_t s);
+
+// Linked blocks without the chain (decode_linked_kernel.hip): blocks [first, first + nblocks) of a frame.
+struct LinkArgs {
+  const uint8_t *src;           // frame bytes (device)
+  const uint64_t *payload_off;  // per block of the frame: payload offset in src
+  const uint32_t *payload_len;
+  const uint32_t *raw;          // per block: nonzero = stored uncompressed
+  uint32_t first, nblocks;
+  uint32_t block_max;
+  uint8_t *dst;                 // frame output (second walk)
+  const uint64_t *start;        // per block: offset of its output in dst (second walk)
+  uint64_t chunk_start;         // output offset that dist[0] stands for
+  uint32_t *dist;               // one zeroed word per output byte of the chunk (second walk)
+  uint32_t dict_len;
+  uint32_t *out_len;            // per block: decoded size
+  int32_t *status;              // per block: 0, or 1 = the block is not for this path
+};
+// plan = false: sizes only; true: literals into dst, match distances into dist
+void launch_link_walk(const LinkArgs &a, bool plan, hipStream_t s);
+// one doubling round over n words; done: one zeroed byte per tile (link_tiles); *moved is set when a word changed
+void launch_link_jump(uint32_t *dist, uint64_t n, uint8_t *done, uint32_t *moved, hipStream_t s);
+void launch_link_gather(const uint32_t *dist, uint64_t n, uint8_t *out, uint64_t chunk_start, const uint8_t *dict,
+                        uint32_t dict_len, hipStream_t s);
+uint64_t link_dist_words(uint64_t n);  // words to allocate (and zero) for n output bytes
+uint64_t link_tiles(uint64_t n);
 // counter: the queue head; order: TWO words per block (queue order, and scratch for building it), or null:
 // index order; order_cnt: two words behind counter in the same array.  The launch zeroes the words it uses (on s).
 // The grid is sized to the wavefronts that stay resident.  form: 0 by launch size, 1 one wavefront per block,

@@ -10,8 +10,9 @@ ctx = N.default_context(0)
 nbytes = 256 << 20
 data = corpus(nbytes // 65536, 65536)
 with_ck = "ck" in sys.argv[1:]  # `ck`: contentChecksum on (hashed on a host thread beside the GPU work)
-o = api._c_options(Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, contentChecksum=with_ck))
-print("contentChecksum:", with_ck, flush=True)
+linked = "linked" in sys.argv[1:]  # `linked`: blockIndependence off (decode: all blocks at once, or LZ4MI_LINK_RESOLVE=0 the chain)
+o = api._c_options(Lz4FrameOptions(blockSize=Lz4FrameBlockSize.k64KB, contentChecksum=with_ck, blockIndependence=not linked))
+print("contentChecksum:", with_ck, "linked:", linked, flush=True)
 cap = L.lz4mi_frame_bound(nbytes, C.byref(o))
 dst = np.empty(cap, dtype=np.uint8)
 back = np.empty(nbytes + 64, dtype=np.uint8)
