@@ -398,12 +398,19 @@ static size_t decode_scratch_budget() {
 // A linked frame of at least this many blocks is decoded all blocks at once (fewer: the chain's one launch is
 // quicker than the fixed cost of the passes).
 constexpr uint32_t kLinkMinBlocks = 4;
-constexpr uint64_t kLinkChunkBytes = 256u << 20;  // output bytes resolved together (four bytes of scratch each)
+// Output bytes resolved together (four bytes of scratch each); LZ4MI_LINK_CHUNK sets another size (tests: several
+// chunks from a small frame).
+static uint64_t link_chunk_bytes() {
+  const char *v = getenv("LZ4MI_LINK_CHUNK");
+  const unsigned long long n = v ? strtoull(v, nullptr, 10) : 0;
+  return n ? n : (256ull << 20);
+}
 
-// LZ4MI_LINK_RESOLVE=0 keeps every linked frame on the chain (for comparisons).
-static bool link_resolve_enabled() {
-  const char *v = getenv("LZ4MI_LINK_RESOLVE");  // read per call: tests switch it between two decodes
-  return !(v && v[0] == '0');
+// LZ4MI_LINK_RESOLVE: 0 = the chain for every linked frame, 2 = a frame that ends up on the chain is an error
+// (tests: the path under test is the one that ran); read per call.
+static int link_resolve_mode() {
+  const char *v = getenv("LZ4MI_LINK_RESOLVE");
+  return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : 1;
 }
 
 // Sizes of all blocks (h_olen, h_stat), then chunk by chunk: literals and distances, doubling rounds until no
@@ -425,9 +432,10 @@ static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_
     total += h_olen[b];
   }
   // scratch: block offsets, tile flags and the moved word, the distance array of the largest chunk
+  const uint64_t chunk_bytes = link_chunk_bytes();
   uint64_t chunk_cap = 0, run = 0;
   for (uint32_t b = 0; b < nb; b++) {  // chunks as the loop below cuts them
-    if (run && run + h_olen[b] > kLinkChunkBytes) {
+    if (run && run + h_olen[b] > chunk_bytes) {
       chunk_cap = run > chunk_cap ? run : chunk_cap;
       run = 0;
     }
@@ -459,7 +467,7 @@ static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_
   while (b0 < nb) {
     uint32_t b1 = b0;
     uint64_t n = 0;
-    while (b1 < nb && (b1 == b0 || n + h_olen[b1] <= kLinkChunkBytes)) n += h_olen[b1++];
+    while (b1 < nb && (b1 == b0 || n + h_olen[b1] <= chunk_bytes)) n += h_olen[b1++];
     la.first = b0;
     la.nblocks = b1 - b0;
     la.chunk_start = starts[b0];
@@ -617,7 +625,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   };
 
   bool resolved = false;
-  if (!indep && nb >= kLinkMinBlocks && (uint64_t)nb * slot <= limit_total + slot && link_resolve_enabled()) {
+  if (!indep && nb >= kLinkMinBlocks && (uint64_t)nb * slot <= limit_total + slot && link_resolve_mode() != 0) {
     // linked blocks, every block at once (decode_linked_kernel.hip); anything but a well-formed frame that fits
     // the limits is left to the chain below
     LinkArgs la;
@@ -637,6 +645,10 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
         if (!fold(b)) break;
       d_frame_out = c->out.as<uint8_t>();
     } else {
+      if (link_resolve_mode() == 2) {
+        c->err = "linked frame left to the chain";
+        return LZ4MI_BACKEND;
+      }
       LZ4MI_HIP(c, hipMemsetAsync(d_olen, 0, (size_t)nb * 8, c->stream));
     }
   }

@@ -26,10 +26,11 @@ def mixed(n, seed):
     return b"".join(parts)[:n]
 
 
-def decode_both(frame, **kw):
-    """(all-at-once result, chain result); each a bytes object or the exception raised."""
+def decode_both(frame, require=True, **kw):
+    """(all-at-once result, chain result); each a bytes object or the exception raised.  With `require` a frame
+    that the all-at-once path hands to the chain is an error (LZ4MI_LINK_RESOLVE=2)."""
     out = []
-    for flag in ("1", "0"):
+    for flag in ("2" if require else "1", "0"):
         os.environ["LZ4MI_LINK_RESOLVE"] = flag
         try:
             out.append(lz4_amd.lz4FrameDecode(frame, **kw))
@@ -70,6 +71,21 @@ def test_linked_frames_decode_like_the_oracle(oracle, name, bs):
         assert fast == data and chain == data
 
 
+@pytest.mark.parametrize("chunk", [65536, 200000, 1 << 20])
+def test_frames_resolved_in_several_chunks(oracle, chunk):
+    """References that cross chunk borders: the bytes in front of a chunk are final when it is resolved."""
+    dictionary = mixed(50000, 70)
+    data = dictionary[-20000:] + mixed(1500000, 71) + bytes(300000) + (b"0123456789abcdef" * 20000) + mixed(400000, 72)
+    o = oracle.frame_options(block_size_id=4, block_independence=False, dict_id=3, content_checksum=True)
+    frame = oracle.frame_encode(data, o, dictionary)
+    os.environ["LZ4MI_LINK_CHUNK"] = str(chunk)
+    try:
+        fast, chain = decode_both(frame, dictionaryResolver=lambda i: dictionary)
+    finally:
+        os.environ.pop("LZ4MI_LINK_CHUNK", None)
+    assert fast == data and chain == data
+
+
 def test_linked_frames_of_the_library_round_trip(oracle):
     data = mixed(2 * 1024 * 1024 + 77, 21)
     for comp in (Lz4FrameCompression.fast, Lz4FrameCompression.hc):
@@ -106,7 +122,7 @@ def test_output_limit_and_damage_report_like_the_chain(oracle):
     o = oracle.frame_options(block_size_id=4, block_independence=False, content_checksum=True, block_checksum=False)
     frame = bytearray(oracle.frame_encode(data, o))
     # an output limit in the middle of the frame
-    fast, chain = decode_both(bytes(frame), maxOutputBytes=300000)
+    fast, chain = decode_both(bytes(frame), require=False, maxOutputBytes=300000)
     assert not isinstance(fast, bytes) and same(fast, chain)
     # damage inside block payloads: whatever the walk makes of it, the report is the chain's (= the reference's)
     rnd = random.Random(61)
@@ -115,7 +131,7 @@ def test_output_limit_and_damage_report_like_the_chain(oracle):
         bad = bytearray(frame)
         at = rnd.randrange(20, len(bad) - 8)
         bad[at] ^= 1 << rnd.randrange(8)
-        fast, chain = decode_both(bytes(bad))
+        fast, chain = decode_both(bytes(bad), require=False)
         assert same(fast, chain), (trial, at, fast, chain)
         try:
             want = oracle.frame_decode(bytes(bad))
