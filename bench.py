@@ -246,6 +246,9 @@ def main():
                     help="BASELINE.json configs index: 1 block round trip (3 with --gpus N), 2 = 4 MiB-block frames "
                          "with checksums, 4 = LZ4HC + dictionary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-by-class", action="store_true",
+                    help="leave out the per-class launches behind the timed region (profiling passes: every launch "
+                         "of a kernel in the profile is then one of the timed shape)")
     args = ap.parse_args()
 
     # stdout carries the one JSON line and nothing else: what libraries print there (RCCL's version banner at
@@ -499,7 +502,7 @@ def main():
             "roofline_all": roof,
             "reference_published": REFERENCE_PUBLISHED,
         }
-        if not multi:
+        if not multi and not args.no_by_class:
             result["roofline_by_class"] = by_class(codec, src, nb, stride, args.acceleration)
         if world == 1 and not multi and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

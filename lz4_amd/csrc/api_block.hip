@@ -1,6 +1,7 @@
 // liblz4mi: context, block-level entry points (single block on host buffers and
 // device-resident batches) and xxHash32.  See include/lz4mi.h for the contract.
 #include "api_common.h"
+#include "frame_host.h"
 
 #include <mutex>
 
@@ -153,6 +154,7 @@ extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   for (DevBuf *b : ctx_buffers(c)) b->release();
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->hash_pin) (void)hipHostFree(c->hash_pin);
   if (c->side_stream) {
     (void)hipStreamSynchronize(c->side_stream);
     (void)hipStreamDestroy(c->side_stream);
@@ -381,10 +383,71 @@ extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_
   return LZ4MI_OK;
 }
 
+namespace lz4mi {
+
+bool hash_on_host(uint64_t n) {
+  const char *v = getenv("LZ4MI_HASH_ENGINE");
+  if (v && v[0] == 'g') return false;
+  if (v && v[0] == 'h') return n != 0;
+  return n >= (4u << 20);
+}
+
+int32_t hash_host_ready(lz4mi_ctx *c) {
+  int32_t st = side_stream_ready(c);
+  if (st) return st;
+  if (!c->hash_pin) LZ4MI_HIP(c, hipHostMalloc(&c->hash_pin, 2 * kHashPiece, hipHostMallocDefault));
+  return LZ4MI_OK;
+}
+
+hipError_t xxh32_device_on_host(lz4mi_ctx *c, const uint8_t *d, uint64_t n, uint32_t seed, uint32_t *out) {
+  hipError_t e = hipSetDevice(c->device);  // this may be a thread of its own
+  if (e != hipSuccess) return e;
+  uint8_t *pin[2] = {(uint8_t *)c->hash_pin, (uint8_t *)c->hash_pin + kHashPiece};
+  lz4mi_xxh32_state st;
+  lz4mi_xxh32_state_init(&st, seed);
+  uint64_t off = 0;
+  uint32_t k = 0;
+  if (n) e = hipMemcpyAsync(pin[0], d, n < kHashPiece ? (size_t)n : kHashPiece, hipMemcpyDeviceToHost, c->side_stream);
+  while (off < n && e == hipSuccess) {
+    const size_t m = n - off < kHashPiece ? (size_t)(n - off) : kHashPiece;
+    e = hipStreamSynchronize(c->side_stream);  // piece k is here
+    if (e != hipSuccess) break;
+    const uint64_t next = off + m;
+    if (next < n)
+      e = hipMemcpyAsync(pin[(k + 1) & 1], d + next, n - next < kHashPiece ? (size_t)(n - next) : kHashPiece,
+                         hipMemcpyDeviceToHost, c->side_stream);
+    xxh_state_update_host(&st, pin[k & 1], m);
+    off = next;
+    k++;
+  }
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(c->side_stream);
+    return e;
+  }
+  *out = lz4mi_xxh32_state_digest(&st);
+  return hipSuccess;
+}
+
+}  // namespace lz4mi
+
 extern "C" int32_t lz4mi_xxh32_device(lz4mi_ctx *c, const uint8_t *d_data, uint64_t len, uint32_t seed,
                                       uint32_t *d_out) {
   if (!c || !d_out) return LZ4MI_RANGE;
   LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  if (::lz4mi::hash_on_host(len)) {
+    // the calling thread hashes; the word reaches d_out in stream order like the kernel's would
+    int32_t st = ::lz4mi::hash_host_ready(c);
+    if (st) return st;
+    st = pin_reserve(c, 256);
+    if (st) return st;
+    LZ4MI_HIP(c, hipEventRecord(c->side_fork, c->stream));
+    LZ4MI_HIP(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+    uint32_t *h = (uint32_t *)((uint8_t *)c->h_pin + 128);
+    LZ4MI_HIP(c, ::lz4mi::xxh32_device_on_host(c, d_data, len, seed, h));
+    LZ4MI_HIP(c, hipMemcpyAsync(d_out, h, 4, hipMemcpyHostToDevice, c->stream));
+    LZ4MI_HIP(c, hipStreamSynchronize(c->stream));  // the pinned word is free again
+    return LZ4MI_OK;
+  }
   launch_xxh32_serial(d_data, len, seed, d_out, c->stream);
   LZ4MI_HIP(c, hipGetLastError());
   return LZ4MI_OK;

@@ -83,6 +83,8 @@ struct lz4mi_ctx {
   // single-stream content checksum of a device-resident source); created on first use.
   hipStream_t side_stream = nullptr;
   hipEvent_t side_fork = nullptr, side_join = nullptr;
+  // two pinned pieces through which device memory reaches a host thread that hashes it (hash_on_host)
+  void *hash_pin = nullptr;
 };
 
 namespace lz4mi {
@@ -126,5 +128,17 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict);
 int32_t pin_reserve(lz4mi_ctx *c, size_t n);
 // makes the side stream and its two events
 int32_t side_stream_ready(lz4mi_ctx *c);
+
+// The content checksum of a frame is ONE xxh32 stream: rounds that each wait for the one before (no way to split
+// it over wavefronts).  One GPU lane-chain runs it at under 2 GB/s; a host core several times faster.  So device
+// memory of this size or more is hashed by a host thread: pieces come over on the side stream into two pinned
+// buffers, a piece is hashed while the next one is on its way.  LZ4MI_HASH_ENGINE=gpu keeps every hash on the
+// device, =host sends every one to the host.
+bool hash_on_host(uint64_t n);
+constexpr size_t kHashPiece = 16u << 20;
+// allocates the pinned pieces and the side stream (calling thread); then, possibly on another thread:
+int32_t hash_host_ready(lz4mi_ctx *c);
+// hashes d[0, n) on the calling thread; the side stream must already wait for whatever produces d
+hipError_t xxh32_device_on_host(lz4mi_ctx *c, const uint8_t *d, uint64_t n, uint32_t seed, uint32_t *out);
 
 }  // namespace lz4mi

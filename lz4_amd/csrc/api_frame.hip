@@ -258,6 +258,22 @@ static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint
   memcpy(c->h_pin, hdr, hlen);
   LZ4MI_HIP(c, hipMemcpyAsync(d_dst, c->h_pin, hlen, hipMemcpyHostToDevice, c->stream));
   LZ4MI_HIP(c, c->words.ensure(64));
+  // device-resident source of some size: a host thread hashes it from pinned pieces (api_common.h: hash_on_host)
+  hipError_t via_host_err = hipSuccess;
+  std::future<uint32_t> via_host;  // joined by its destructor on every return path
+  if (o->content_checksum && !host_hash && hash_on_host(n)) {
+    st = hash_host_ready(c);
+    if (st) return st;
+    LZ4MI_HIP(c, hipEventRecord(c->side_fork, c->stream));  // whatever produced d_src on this stream is done
+    LZ4MI_HIP(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
+    hipError_t *ep = &via_host_err;
+    via_host = std::async(std::launch::async, [c, d_src, n, ep] {
+      uint32_t h = 0;
+      *ep = xxh32_device_on_host(c, d_src, n, 0, &h);
+      return h;
+    });
+    host_hash = &via_host;
+  }
   const bool side = o->content_checksum && !host_hash;
   if (side) {  // Xxh32 over all uncompressed content (:148,163,266)
     st = side_stream_ready(c);
@@ -278,6 +294,7 @@ static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint
   if (o->content_checksum && host_hash) {
     uint32_t *h = (uint32_t *)((uint8_t *)c->h_pin + 64);
     *h = host_hash->get();
+    LZ4MI_HIP(c, via_host_err);
     LZ4MI_HIP(c, hipMemcpyAsync(c->words.p, h, 4, hipMemcpyHostToDevice, c->stream));
   }
   // end mark (:263) [+ content checksum] behind the last record

@@ -7,10 +7,10 @@ out=gpurun_out/profiles_new
 rm -rf $out && mkdir -p $out
 export TMPDIR=/tmp
 timeout -k 10 400 python bench.py > $out/bench.json 2> $out/bench.err
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -f csv -- python bench.py --no-cpu-baseline --steps 12 --warmup 1 > $out/trace.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/trace -o t -f csv -- python bench.py --no-cpu-baseline --no-by-class --steps 12 --warmup 1 > $out/trace.log 2>&1
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f -f csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/pmc_fetch.log 2>&1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w -f csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 1 > $out/pmc_write.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_fetch -o f -f csv -- python bench.py --no-cpu-baseline --no-by-class --steps 3 --warmup 1 > $out/pmc_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_write -o w -f csv -- python bench.py --no-cpu-baseline --no-by-class --steps 3 --warmup 1 > $out/pmc_write.log 2>&1
 cp $(find $out/pmc_fetch -name "*counter_collection.csv" | head -1) $out/pmc_fetch.csv
 cp $(find $out/pmc_write -name "*counter_collection.csv" | head -1) $out/pmc_write.csv
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write

@@ -20,7 +20,7 @@ f, w = per_kernel(f"{d}/pmc_fetch.csv", "FETCH_SIZE"), per_kernel(f"{d}/pmc_writ
 res = {}
 for k in f:
     fetch, write = int(f[k] * 1024 * 2), int(w[k] * 1024)
-    res[k] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+    res[k] = {"hbm_bytes_per_launch": fetch + write, "blocks_per_launch": 16384, "fetch_bytes_corrected": fetch, "write_bytes": write,
               "FETCH_SIZE_KiB_raw": f[k], "WRITE_SIZE_KiB_raw": w[k],
               "note": "rocprofv3 --pmc, separate passes over bench.py (16384 blocks/launch, scripts/collect_profiles.sh); "
                       "FETCH_SIZE (KiB) doubled per the gfx950 correction"}
