@@ -16,12 +16,23 @@
 // table (position j and j+d hash the same bytes and j+d is inserted later), so
 // the interior re-hash (:139-145) touches min(length-4, d) positions.
 //
-// Table: 65536 x u32 per wavefront slot in HBM/L2, entry = generation<<24 | (pos+1);
-// a stale generation reads as empty, so a slot is reused without clearing.  Blocks whose positions
-// do not fit 24 bits (dictionary + block of 16 MiB and more: one lz4Compress call on a large buffer)
-// run the WIDE variant: entry = pos+1, the slot cleared in front of the block.
+// Table: 65536 x u32 per wavefront slot in HBM/L2.  Three entry formats, one per launch:
+//   * generation<<24 | (pos+1)<<7 | tag   while every position of block and dictionary fits 17 bits (TAG): the
+//     tag is seven bits of the hashed sequence that the bucket index does not cover, so a candidate whose tag
+//     differs is dropped without fetching its bytes.  The tag sits below the position because inserts are
+//     maxima: a larger position must compare larger whatever the tags are;
+//   * generation<<24 | (pos+1)            up to 16 MiB;
+//   * pos+1                               above that (WIDE: one lz4Compress call on a large buffer), the slot
+//     cleared in front of the block.
+// A stale generation reads as empty, so a slot is reused without clearing.
 // A shared dictionary is primed once into a read-only table consulted when the
 // slot entry is empty (dictionary positions are always smaller than block positions).
+//
+// Two code paths produce the same bytes.  The general path takes any sequence: ten probes in the first step,
+// 64 at a time after that, dictionary and linked history, references anywhere.  In front of it stands a short
+// path (fast_sequence) for the case that nine of ten sequences of match-rich data are: it checks every one of
+// its assumptions before its first write, so a sequence it cannot take starts over in the general path with
+// nothing to undo.
 #include "encode_common.h"
 #include "profile.h"
 
