@@ -220,6 +220,55 @@ def by_class(codec, src, nb, stride, acceleration):
     return out
 
 
+def pipelined_round_trip(codec, src, nb, stride, acceleration, slots, out, steps):
+    """The same round trip with the steps software-pipelined over two contexts (not the headline: `value` times the
+    steps one after the other).  The encode of step k+1 is launched behind the encode of step k, the decode of
+    step k on a second context's stream behind its own encode, into double-buffered slots and outputs: the decode
+    then runs beside the next encode launch, whose second half leaves wavefront slots free behind its longest
+    blocks.  What a caller that streams batches through the codec gets."""
+    from lz4_amd.device import DeviceCodec
+    dec = DeviceCodec(codec.device)
+    dec.fence = False
+    dev = src.device
+    slots2 = [slots, torch.empty_like(slots)]
+    out2 = [out, torch.empty_like(out)]
+
+    def run(n):
+        done, hold = [None, None], []
+        for k in range(n):
+            b = k & 1
+            with torch.cuda.stream(codec.stream):
+                if done[b] is not None:
+                    codec.stream.wait_event(done[b])  # the decode that read these slots two steps ago
+                s, sizes, st_c = codec.compress_blocks(src, BLOCK, acceleration=acceleration, out=slots2[b])
+                e = torch.cuda.Event()
+                e.record(codec.stream)
+            with torch.cuda.stream(dec.stream):
+                dec.stream.wait_event(e)
+                o, out_len, st_d = dec.decompress_blocks(s, sizes, BLOCK, comp_stride=stride, strict=True, out=out2[b])
+                d = torch.cuda.Event()
+                d.record(dec.stream)
+            done[b] = d
+            hold.append((sizes, st_c, out_len, st_d))  # kept until the launches that use them have run
+        torch.cuda.synchronize()
+        return hold
+
+    run(3)
+    t0 = time.perf_counter()
+    hold = run(steps)
+    wall = time.perf_counter() - t0
+    for sizes, st_c, out_len, st_d in hold[-2:]:
+        assert int(st_c.abs().sum()) == 0 and int(st_d.abs().sum()) == 0
+    for o in out2:
+        flat = o.reshape(-1)
+        for lo in range(0, src.numel(), 1 << 30):
+            assert torch.equal(flat[lo:lo + (1 << 30)], src[lo:lo + (1 << 30)]), "pipelined decode(encode(x)) != x"
+    del dec
+    return {"value": nb * BLOCK * steps / wall / 1e9, "unit": "GB/s", "ms_per_step": wall / steps * 1e3, "steps": steps,
+            "note": "steps overlapped over two contexts (decode of step k beside the encode of step k+1); "
+                    "not the headline, which runs the steps one after the other"}
+
+
 def traffic_of(kernel, blocks_per_launch, phase):
     """HBM bytes per launch from the PMC passes, or None when they profiled another launch shape than this run's
     (another number of blocks per launch, or the sharded step's window kernels)."""
@@ -502,6 +551,9 @@ def main():
             "roofline_all": roof,
             "reference_published": REFERENCE_PUBLISHED,
         }
+        if not multi and not args.no_by_class and nb <= 32768:
+            result["pipelined_round_trip"] = pipelined_round_trip(codec, src, nb, stride, args.acceleration, slots, out,
+                                                                  args.steps)
         if not multi and not args.no_by_class:
             result["roofline_by_class"] = by_class(codec, src, nb, stride, args.acceleration)
         if world == 1 and not multi and not args.no_cpu_baseline:

@@ -842,10 +842,17 @@ struct EncodeKArgs {
 };
 typedef const volatile __attribute__((address_space(4))) EncodeKArgs *EncodeKArgsPtr;
 
+// Wavefronts of one workgroup share nothing but the workgroup's LDS allocation, which the CU gets back only
+// when the last of them has ended.
+#ifndef LZ4MI_ENC_WPW
+#define LZ4MI_ENC_WPW 4
+#endif
+constexpr uint32_t kEncWpw = LZ4MI_ENC_WPW;  // wavefronts per workgroup
+
 template <bool HAS_DICT, bool LINKED, bool WIDE = false, bool TAG = false>
-__global__ __launch_bounds__(256) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_win[4][kWinBytes + kWinPad];
-  __shared__ uint32_t s_claim[4][kClaimSlots];
+__global__ __launch_bounds__(64 * kEncWpw) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_win[kEncWpw][kWinBytes + kWinPad];
+  __shared__ uint32_t s_claim[kEncWpw][kClaimSlots];
   EncodeKArgsPtr ka = (EncodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
   const uint32_t lane = lane_id();
   const uint32_t wave = uni(threadIdx.x / kWave);
@@ -968,22 +975,23 @@ void launch_encode_fast(const BatchArgs &a, uint32_t accel_shift, const EncodeSc
   const bool wide = !a.src_len && !a.linked && (uint64_t)a.src_len_uniform + a.dict_len > kPosMask - 2;
   // every position of every block fits the tagged entry's 17 bits (uniform block length known here)
   const bool tag = !a.src_len && (uint64_t)a.src_len_uniform + (a.linked ? 65535u : a.dict_len) <= kTagPosMask;
+  const uint32_t wgs = grid * 4u / kEncWpw;  // `grid` counts groups of four wavefronts
   if (tag && a.linked)
-    hipLaunchKernelGGL((encode_fast_kernel<true, true, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<true, true, false, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (tag && a.dict_len)
-    hipLaunchKernelGGL((encode_fast_kernel<true, false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<true, false, false, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (tag)
-    hipLaunchKernelGGL((encode_fast_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<false, false, false, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (wide && a.dict_len)
-    hipLaunchKernelGGL((encode_fast_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<true, false, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (wide)
-    hipLaunchKernelGGL((encode_fast_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<false, false, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (a.linked)
-    hipLaunchKernelGGL((encode_fast_kernel<true, true>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<true, true>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else if (a.dict_len)
-    hipLaunchKernelGGL((encode_fast_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<true, false>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
   else
-    hipLaunchKernelGGL((encode_fast_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, accel_shift, sc, counter);
+    hipLaunchKernelGGL((encode_fast_kernel<false, false>), dim3(wgs), dim3(64 * kEncWpw), 0, s, a, accel_shift, sc, counter);
 }
 
 }  // namespace lz4mi

@@ -21,13 +21,15 @@ def _ptr(t):
 
 
 class DeviceCodec:
-    def __init__(self, device: int | None = None):
+    def __init__(self, device: int | None = None, priority: int = 0):
         if not torch.cuda.is_available():
             raise N.Lz4BackendError("no GPU visible to torch: the device codec needs an MI355X")
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.torch_device = torch.device("cuda", self.device)
         # the codec's own stream; calls are fenced against torch's current stream on entry and exit
-        self.stream = torch.cuda.Stream(self.torch_device)
+        # (priority: torch's stream priority, -1 = high; a caller that overlaps launches of two codecs gives the
+        # one whose launch should get the wavefront slots first the high one)
+        self.stream = torch.cuda.Stream(self.torch_device, priority=priority)
         self.ctx = N.Context(self.device, self.stream.cuda_stream)
         self.L = N.load()
         self.fence = True  # set False to manage stream ordering yourself (benchmarks)

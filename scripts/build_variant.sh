@@ -5,11 +5,11 @@ set -e
 cd "$(dirname "$0")/../lz4_amd/csrc"
 name=$1; flags=$2
 mkdir -p build_$name
-SRCS="decode_kernel.hip encode_fast_kernel.hip encode_hc_kernel.hip xxh32_kernel.hip frame_kernels.hip api_block.hip api_frame.hip api_stream.hip"
+SRCS="decode_kernel.hip decode_linked_kernel.hip encode_fast_kernel.hip encode_hc_kernel.hip xxh32_kernel.hip frame_kernels.hip api_block.hip api_frame.hip api_stream.hip"
 for f in $SRCS; do
   o=build_$name/${f%.hip}.o
   case $f in
-    decode_kernel.hip|encode_fast_kernel.hip|encode_hc_kernel.hip|xxh32_kernel.hip) hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $flags -c $f -o $o & ;;
+    decode_kernel.hip|decode_linked_kernel.hip|encode_fast_kernel.hip|encode_hc_kernel.hip|xxh32_kernel.hip) hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result $flags -c $f -o $o & ;;
     *) [ build/${f%.hip}.o -nt $f ] && cp build/${f%.hip}.o $o || hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -c $f -o $o & ;;
   esac
 done
