@@ -222,7 +222,11 @@ int32_t lz4mi_set_decode_form(int32_t form);
 int32_t lz4mi_xxh32_batch(lz4mi_ctx *ctx, const lz4mi_batch *b, uint32_t *d_hash);
 
 /* Single-stream xxh32 over device memory (content checksum,
- * lib/src/frame/lz4_frame_encoder.dart:148,163,266; lz4_frame_decoder.dart:311). */
+ * lib/src/frame/lz4_frame_encoder.dart:148,163,266; lz4_frame_decoder.dart:311).  The word is written to
+ * d_out in stream order.  One xxh32 stream is a chain of dependent rounds that a host core runs several times
+ * faster than a GPU wavefront, so inputs of 4 MiB and more are copied to pinned host memory in pieces (on a side
+ * stream) and hashed by the calling thread: the call then returns when the hash is done.  LZ4MI_HASH_ENGINE=gpu
+ * in the environment keeps every size on the device and the call asynchronous (needed under stream capture). */
 int32_t lz4mi_xxh32_device(lz4mi_ctx *ctx, const uint8_t *d_data, uint64_t len, uint32_t seed,
                            uint32_t *d_out);
 

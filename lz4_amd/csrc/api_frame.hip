@@ -431,10 +431,10 @@ static int link_resolve_mode() {
 }
 
 // Sizes of all blocks (h_olen, h_stat), then chunk by chunk: literals and distances, doubling rounds until no
-// distance moves, the copied bytes.  *resolved = false when a block is not for this path (the output buffer may
+// distance moves, the copied bytes.  h_word: a pinned word for the "something moved" read-back.  *resolved = false when a block is not for this path (the output buffer may
 // hold partial data then; the chain writes all of it again).
 static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_t *d_dict, uint32_t *h_olen,
-                            int32_t *h_stat, bool *resolved) {
+                            int32_t *h_stat, uint32_t *h_word, bool *resolved) {
   *resolved = false;
   const uint64_t slot = la.block_max;
   la.first = 0;
@@ -479,7 +479,6 @@ static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_
   la.dst = c->out.as<uint8_t>();
   la.start = d_start;
   la.dist = d_dist;
-  uint32_t *h_word = (uint32_t *)c->h_pin + (c->h_pin_cap / 4 - 1);  // last word of the pinned scratch
   uint32_t b0 = 0;
   while (b0 < nb) {
     uint32_t b1 = b0;
@@ -655,7 +654,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     la.dict_len = (uint32_t)(d_dict ? dict_len : 0);
     la.out_len = d_olen;
     la.status = d_stat;
-    st = link_resolve(c, la, nb, d_dict, h_olen, h_stat, &resolved);
+    st = link_resolve(c, la, nb, d_dict, h_olen, h_stat, (uint32_t *)((uint8_t *)c->h_pin + hb + 32), &resolved);
     if (st) return st;
     if (resolved) {
       for (uint32_t b = 0; b < nb; b++)
