@@ -4,6 +4,7 @@
 #include "frame_host.h"
 
 #include <mutex>
+#include <thread>
 
 using namespace lz4mi;
 
@@ -155,6 +156,8 @@ extern "C" void lz4mi_ctx_destroy(lz4mi_ctx *c) {
   if (c->d_counters) (void)hipFree(c->d_counters);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->hash_pin) (void)hipHostFree(c->hash_pin);
+  for (hipStream_t &cs : c->copy_streams)
+    if (cs) (void)hipStreamDestroy(cs);
   if (c->side_stream) {
     (void)hipStreamSynchronize(c->side_stream);
     (void)hipStreamDestroy(c->side_stream);
@@ -384,6 +387,39 @@ extern "C" int32_t lz4mi_xxh32_batch(lz4mi_ctx *c, const lz4mi_batch *b, uint32_
 }
 
 namespace lz4mi {
+
+int32_t host_copy(lz4mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind kind) {
+  if (!n) return LZ4MI_OK;
+  if (kind == hipMemcpyDeviceToHost) LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  constexpr size_t kParallelMin = 8u << 20;
+  constexpr unsigned kThreads = 4;
+  if (n < kParallelMin) {  // in stream order; a host-to-device copy is not waited for (the runtime has read src)
+    LZ4MI_HIP(c, hipMemcpyAsync(dst, src, n, kind, c->stream));
+    if (kind == hipMemcpyDeviceToHost) LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+    return LZ4MI_OK;
+  }
+  for (hipStream_t &cs : c->copy_streams)
+    if (!cs) LZ4MI_HIP(c, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  // the slices go over streams of their own: nothing queued on the context's stream may still touch either side
+  if (kind != hipMemcpyDeviceToHost) LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t slice = round_up((n + kThreads - 1) / kThreads, 4096);
+  hipError_t err[kThreads];
+  auto part = [&](unsigned k) {
+    const size_t lo = (size_t)k * slice;
+    if (lo >= n) { err[k] = hipSuccess; return; }
+    const size_t m = n - lo < slice ? n - lo : slice;
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = hipMemcpyAsync((uint8_t *)dst + lo, (const uint8_t *)src + lo, m, kind, c->copy_streams[k]);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->copy_streams[k]);
+    err[k] = e;
+  };
+  std::thread helpers[kThreads - 1];
+  for (unsigned k = 1; k < kThreads; k++) helpers[k - 1] = std::thread(part, k);
+  part(0);
+  for (std::thread &t : helpers) t.join();
+  for (unsigned k = 0; k < kThreads; k++) LZ4MI_HIP(c, err[k]);
+  return LZ4MI_OK;
+}
 
 bool hash_on_host(uint64_t n) {
   const char *v = getenv("LZ4MI_HASH_ENGINE");

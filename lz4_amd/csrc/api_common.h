@@ -85,6 +85,8 @@ struct lz4mi_ctx {
   hipEvent_t side_fork = nullptr, side_join = nullptr;
   // two pinned pieces through which device memory reaches a host thread that hashes it (hash_on_host)
   void *hash_pin = nullptr;
+  // streams of the host threads that share a large copy to or from pageable host memory (host_copy)
+  hipStream_t copy_streams[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 namespace lz4mi {
@@ -128,6 +130,14 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict);
 int32_t pin_reserve(lz4mi_ctx *c, size_t n);
 // makes the side stream and its two events
 int32_t side_stream_ready(lz4mi_ctx *c);
+
+// Bulk copy between the caller's host memory and the device: a device-to-host copy first waits for the context's
+// stream and returns when the bytes have arrived; a host-to-device copy returns when src may be reused and is
+// ordered in front of whatever the caller queues on the context's stream next.  A copy of pageable memory is staged
+// by the calling thread, which is what bounds it (17.6 GB/s device to host, 29 GB/s host to device on the GPU box);
+// from 8 MiB on the range is cut into four slices that four host threads copy at once on streams of their own
+// (43.5 and 42 GB/s).
+int32_t host_copy(lz4mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyKind kind);
 
 // The content checksum of a frame is ONE xxh32 stream: rounds that each wait for the one before (no way to split
 // it over wavefronts).  One GPU lane-chain runs it at under 2 GB/s; a host core several times faster.  So device

@@ -333,7 +333,8 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   const size_t fb = lz4mi_frame_bound(n, o);
   LZ4MI_HIP(c, c->in.ensure(n + 16));
   LZ4MI_HIP(c, c->out.ensure(fb + 16));
-  if (n) LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, src, n, hipMemcpyHostToDevice, c->stream));
+  st = host_copy(c, c->in.p, src, n, hipMemcpyHostToDevice);
+  if (st) return st;
   const uint8_t *d_dict = nullptr;
   if (dict && dict_len) {
     LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
@@ -347,8 +348,8 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
                                 &total, o->content_checksum ? &content_hash : nullptr);
   if (st && st != LZ4MI_FORMAT_CONTENT_SIZE_ARG) return st;
   if (total > cap) return LZ4MI_DST_TOO_SMALL;
-  LZ4MI_HIP(c, hipMemcpyAsync(dst, c->out.p, total, hipMemcpyDeviceToHost, c->stream));
-  LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
+  st = host_copy(c, dst, c->out.p, total, hipMemcpyDeviceToHost);
+  if (st) return st;
   if (out_len) *out_len = total;
   // raised after all the work, like the reference (:269-271)
   if (o->has_content_size && (uint64_t)n != o->content_size) return LZ4MI_FORMAT_CONTENT_SIZE_ARG;
@@ -540,7 +541,10 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     return LZ4MI_OK;
   }
   LZ4MI_HIP(c, c->in.ensure(region_len + 16));
-  LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, region, region_len, hipMemcpyHostToDevice, c->stream));
+  {
+    const int32_t up = host_copy(c, c->in.p, region, region_len, hipMemcpyHostToDevice);
+    if (up) return up;
+  }
   const uint8_t *d_dict = nullptr;
   if (have_dict && dict_len) {
     if (dict_len > 65536) {  // the decoder keeps the last 65536 bytes (lz4_frame_decoder.dart:278-282)
@@ -792,9 +796,9 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     hipError_t e = hipSuccess;
     for (size_t off = 0; off < produced && e == hipSuccess; off += piece) {
       const size_t m = produced - off < piece ? (size_t)(produced - off) : piece;
-      e = hipMemcpyAsync(dst + off, d_frame_out + off, m, hipMemcpyDeviceToHost, c->stream);
-      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      const int32_t down = host_copy(c, dst + off, d_frame_out + off, m, hipMemcpyDeviceToHost);
       if (hashing.valid()) hashing.get();
+      if (down) return down;
       if (e == hipSuccess) {
         lz4mi_xxh32_state *hp = &hs;
         const uint8_t *q = dst + off;
@@ -805,7 +809,8 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     LZ4MI_HIP(c, e);
     *content_hash = lz4mi_xxh32_state_digest(&hs);
   } else {
-    if (produced) LZ4MI_HIP(c, hipMemcpyAsync(dst, d_frame_out, produced, hipMemcpyDeviceToHost, c->stream));
+    const int32_t down = host_copy(c, dst, d_frame_out, produced, hipMemcpyDeviceToHost);
+    if (down) return down;
     LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
   }
   if (extras) extras->d_out = d_frame_out;

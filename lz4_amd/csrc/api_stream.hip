@@ -232,7 +232,8 @@ extern "C" int32_t lz4mi_legacy_frame_encode(lz4mi_ctx *c, const uint8_t *src, s
   LZ4MI_HIP(c, c->status.ensure((size_t)nb * 4));
   int32_t st = pin_reserve(c, (size_t)nb * 8 + 64);
   if (st) return st;
-  LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, src, n, hipMemcpyHostToDevice, c->stream));
+  st = host_copy(c, c->in.p, src, n, hipMemcpyHostToDevice);
+  if (st) return st;
   BatchArgs a;
   memset(&a, 0, sizeof a);
   a.src = c->in.as<uint8_t>();
@@ -329,7 +330,8 @@ int32_t enc_emit(lz4mi_frame_encoder *e, size_t n, uint8_t *dst, size_t cap, siz
   int32_t st = encode_records(c, e->buf + kHistoryWindow, n, &e->o, d_dict, dlen, c->out.as<uint8_t>(), 0, &end);
   if (st) return st;
   if (end > cap) return LZ4MI_DST_TOO_SMALL;
-  if (end) LZ4MI_HIP(c, hipMemcpyAsync(dst, c->out.p, end, hipMemcpyDeviceToHost, c->stream));
+  st = host_copy(c, dst, c->out.p, end, hipMemcpyDeviceToHost);
+  if (st) return st;
   LZ4MI_HIP(c, hipStreamSynchronize(c->stream));
   *out_len = end;
   return LZ4MI_OK;
@@ -397,7 +399,8 @@ extern "C" int32_t lz4mi_frame_encoder_update(lz4mi_frame_encoder *e, const uint
   int32_t st = enc_reserve(e, e->pending + n);
   if (st) return st;
   uint8_t *d_chunk = e->buf + kHistoryWindow + e->pending;
-  LZ4MI_HIP(c, hipMemcpyAsync(d_chunk, chunk, n, hipMemcpyHostToDevice, c->stream));
+  st = host_copy(c, d_chunk, chunk, n, hipMemcpyHostToDevice);
+  if (st) return st;
   // :168-170: the chunk is host memory; its content-checksum rounds run on a host thread while the GPU encodes
   // the blocks this chunk completes (joined before the call returns, on every path)
   struct Join {
