@@ -249,7 +249,8 @@ namespace lz4mi {
 // hashes it on the context's side stream, beside the block launches (it depends on nothing but d_src).
 static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint64_t n, const lz4mi_frame_options *o,
                                         const uint8_t *d_dict, uint32_t dict_len, uint8_t *d_dst, uint64_t cap,
-                                        uint64_t *out_len, std::future<uint32_t> *host_hash) {
+                                        uint64_t *out_len, std::future<uint32_t> *host_hash,
+                                        bool patch_later = false) {
   if (cap < lz4mi_frame_bound((size_t)n, o)) return LZ4MI_DST_TOO_SMALL;
   uint8_t hdr[32];
   const size_t hlen = build_header(o, hdr);
@@ -291,7 +292,10 @@ static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint
     if (!st) LZ4MI_HIP(c, e);
   }
   if (st) return st;
-  if (o->content_checksum && host_hash) {
+  if (o->content_checksum && host_hash && patch_later) {
+    // the caller downloads the frame while the hash is still running and writes the word into its copy
+    LZ4MI_HIP(c, hipMemsetAsync(c->words.p, 0, 4, c->stream));
+  } else if (o->content_checksum && host_hash) {
     uint32_t *h = (uint32_t *)((uint8_t *)c->h_pin + 64);
     *h = host_hash->get();
     LZ4MI_HIP(c, via_host_err);
@@ -345,11 +349,15 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   }
   uint64_t total = 0;
   st = frame_encode_device_impl(c, c->in.as<uint8_t>(), n, o, d_dict, (uint32_t)dict_len, c->out.as<uint8_t>(), fb,
-                                &total, o->content_checksum ? &content_hash : nullptr);
+                                &total, o->content_checksum ? &content_hash : nullptr, true);
   if (st && st != LZ4MI_FORMAT_CONTENT_SIZE_ARG) return st;
   if (total > cap) return LZ4MI_DST_TOO_SMALL;
   st = host_copy(c, dst, c->out.p, total, hipMemcpyDeviceToHost);
   if (st) return st;
+  if (o->content_checksum) {  // the frame's last word (:266), from the host thread that hashed src meanwhile
+    const uint32_t h = content_hash.get();
+    for (int k = 0; k < 4; k++) dst[total - 4 + k] = (uint8_t)(h >> (8 * k));
+  }
   if (out_len) *out_len = total;
   // raised after all the work, like the reference (:269-271)
   if (o->has_content_size && (uint64_t)n != o->content_size) return LZ4MI_FORMAT_CONTENT_SIZE_ARG;
