@@ -125,7 +125,9 @@ int32_t lz4mi_block_decompress_into(lz4mi_ctx *ctx, const uint8_t *src, size_t c
                                     uint8_t *dst, size_t prefix_len, size_t max_len,
                                     size_t *out_len);
 
-/* xxh32  lib/src/xxhash/xxh32.dart:166-240 (one-shot, host buffer, computed on the GPU). */
+/* xxh32  lib/src/xxhash/xxh32.dart:166-240 (one-shot, host buffer).  One xxh32 stream is a chain of dependent
+ * rounds: inputs below 4 MiB go to the device kernel, larger ones are hashed where they are, by the calling thread
+ * (several times a GPU wavefront's rate, and no copy); LZ4MI_HASH_ENGINE=gpu keeps every size on the device. */
 int32_t lz4mi_xxh32(lz4mi_ctx *ctx, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out);
 
 /* Xxh32 (streaming)  lib/src/xxhash/xxh32.dart:21-164.  Plain data owned by the caller:

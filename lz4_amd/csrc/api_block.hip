@@ -508,7 +508,8 @@ int32_t one_block(lz4mi_ctx *c, const uint8_t *src, size_t n, const uint8_t *dic
   LZ4MI_HIP(c, c->status.ensure(16));
   int32_t st = pin_reserve(c, 64);
   if (st) return st;
-  if (n) LZ4MI_HIP(c, hipMemcpyAsync(c->in.p, src, n, hipMemcpyHostToDevice, c->stream));
+  st = host_copy(c, c->in.p, src, n, hipMemcpyHostToDevice);
+  if (st) return st;
   if (dict_len) {
     LZ4MI_HIP(c, c->dictbuf.ensure(dict_len));
     LZ4MI_HIP(c, hipMemcpyAsync(c->dictbuf.p, dict, dict_len, hipMemcpyHostToDevice, c->stream));
@@ -604,6 +605,13 @@ extern "C" int32_t lz4mi_block_decompress_into(lz4mi_ctx *c, const uint8_t *src,
 extern "C" int32_t lz4mi_xxh32(lz4mi_ctx *c, const uint8_t *data, size_t len, uint32_t seed, uint32_t *out) {
   if (!c || !out) return LZ4MI_RANGE;
   LZ4MI_HIP(c, ::lz4mi::enter_device(c));
+  if (::lz4mi::hash_on_host(len)) {  // one serial stream over bytes that are in host memory already (api_common.h)
+    lz4mi_xxh32_state hs;
+    lz4mi_xxh32_state_init(&hs, seed);
+    ::lz4mi::xxh_state_update_host(&hs, data, len);
+    *out = lz4mi_xxh32_state_digest(&hs);
+    return LZ4MI_OK;
+  }
   LZ4MI_HIP(c, c->in.ensure(len + 16));
   LZ4MI_HIP(c, c->words.ensure(64));
   int32_t st = pin_reserve(c, 64);

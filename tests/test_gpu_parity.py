@@ -60,6 +60,25 @@ def test_xxh32_lengths_vs_oracle(lz, oracle):
             assert lz.xxh32(d, seed) == oracle.xxh32(d, seed), n
 
 
+def test_xxh32_single_stream_on_both_engines(lz, codec, oracle):
+    """One stream of 4 MiB and more is hashed by a host thread (host data where it is, device data from pinned
+    pieces), smaller ones and LZ4MI_HASH_ENGINE=gpu by the device kernel: same word either way."""
+    import torch
+    rng = np.random.default_rng(12)
+    for n in (4 * 1024 * 1024 - 1, 5 * 1024 * 1024 + 13, 33 * 1024 * 1024 + 7):
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        want = oracle.xxh32(d.tobytes(), 0x1234567)
+        t = torch.from_numpy(d).cuda()
+        for engine in (None, "gpu", "host"):
+            if engine:
+                os.environ["LZ4MI_HASH_ENGINE"] = engine
+            try:
+                assert lz.xxh32(d.tobytes(), 0x1234567) == want, (n, engine)
+                assert (int(codec.xxh32(t, 0x1234567)[0]) & 0xFFFFFFFF) == want, (n, engine)
+            finally:
+                os.environ.pop("LZ4MI_HASH_ENGINE", None)
+
+
 @pytest.mark.parametrize("repeat", [3, 160])  # 48 blocks: a wavefront per block; 2560: sixteen blocks per wavefront
 def test_xxh32_batch_vs_oracle(codec, oracle, repeat):
     import torch
