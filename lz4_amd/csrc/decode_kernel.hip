@@ -775,7 +775,10 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
     bp.general = nbad <= nover || nb == 0u;  // a first sequence that is a batch of its own and more: general loop
     pc.have_win = true;
     bp.ip_stop = (uint32_t)wb + rdlane(ta, nb);
-  } else if (nreal < count && nnok <= nbrk) {  // a token that is not for the batch
+  } else if (nreal < count && nnok < nbrk) {  // a token that is not for the batch
+    // (strictly in front of the place where the list leaves the real chain: with nnok == nbrk the list entry at
+    // nnok is not a token at all, it only parsed as one that a batch cannot take, and the block goes on at the
+    // real successor of the sequence in front of it, below)
     const uint32_t at = rdlane(ta, nreal);
     bp.ip_stop = (uint32_t)wb + at;
     bp.general = (uint32_t)(wb + (int32_t)kCw) >= in_end || at < 16u;

@@ -53,3 +53,34 @@ def build_frame(flg, bd, blocks, xxh32, add_content_checksum=False, content_size
 
 # ---------------------------------------------------------------- corpus
 from tools.corpus import corpus, corpus_block  # noqa: E402,F401  (C generator, tools/corpus.c)
+
+
+# ---------------------------------------------------------------- hand-built compressed blocks
+def lz4_length(base, n):
+    """Token nibble and extension bytes of a length (lib/src/block/lz4_block_decoder.dart:121-130)."""
+    if n < base + 15:
+        return n - base, b""
+    rest = n - base - 15
+    return 15, bytes([255] * (rest // 255) + [rest % 255])
+
+
+def block_of_sequences(seqs, rng, prefix=b""):
+    """(compressed block, decoded bytes) for a list of (literal length, match length, distance); a match length of 0
+    ends the block with that literal run.  Distances are clamped to what the block may reach (prefix included).
+    Sequences no encoder here writes: any number of extension bytes, any distance, overlapping matches."""
+    out, comp = bytearray(), bytearray()
+    for ll, ml, dist in seqs:
+        lits = rng.randbytes(ll)
+        lnib, lext = lz4_length(0, ll)
+        if ml == 0:
+            comp += bytes([lnib << 4]) + lext + lits
+            out += lits
+            break
+        dist = max(1, min(dist, len(prefix) + len(out) + ll, 65535))
+        mnib, mext = lz4_length(4, ml)
+        comp += bytes([(lnib << 4) | mnib]) + lext + lits + bytes([dist & 255, dist >> 8]) + mext
+        out += lits
+        for _ in range(ml):  # lib/src/internal/byte_writer.dart:116-118
+            p = len(out) - dist
+            out.append(out[p] if p >= 0 else prefix[len(prefix) + p])
+    return bytes(comp), bytes(out)

@@ -13,7 +13,7 @@ import pytest
 
 import lz4_amd
 from lz4_amd import Lz4FrameBlockSize, Lz4FrameCompression, Lz4FrameOptions
-from tests.helpers import corpus_block
+from tests.helpers import build_frame, corpus_block, lz4_length as _length
 
 pytestmark = pytest.mark.gpu
 
@@ -143,3 +143,66 @@ def test_output_limit_and_damage_report_like_the_chain(oracle):
             assert not isinstance(fast, bytes) and type(fast).__name__ == want.type_name and fast.message == want.message
             differing += 1
     assert differing > 0
+
+
+# ------------------------------------------------------------------ hand-built sequences
+def synthetic_block(rng, history, target, end_after_match):
+    """A compressed block of `target` decoded bytes made of sequences no encoder here writes: literal and match
+    lengths with up to four extension bytes, distances from 1 to everything the block may reach, overlapping
+    matches, and optionally an end right behind a match (lz4BlockDecompressInto returns at end of input)."""
+    out = bytearray()       # decoded bytes of this block
+    comp = bytearray()
+    hist = bytes(history[-65536:])
+    while len(out) < target:
+        left = target - len(out)
+        ll = min(left, rng.choice([0, 0, 1, 3, 14, 15, 16, 40, 269, 270, 271, 300, 525, 1100, 5000]))
+        lits = rng.randbytes(ll)
+        reach = len(hist) + len(out) + ll
+        want_match = left - ll >= 4 and reach > 0
+        if not want_match:
+            ll = left  # the block's last sequence: literals only
+            lits = rng.randbytes(ll)
+            nib, ext = _length(0, ll)
+            comp += bytes([nib << 4]) + ext + lits
+            out += lits
+            break
+        ml = min(left - ll, rng.choice([4, 4, 5, 8, 18, 19, 20, 64, 273, 274, 275, 600, 1300, 4000]))
+        dist = rng.choice([1, 2, 3, 7, 31, 64, 255, 256, 4095, 65535, rng.randrange(1, 65536), reach])
+        dist = max(1, min(dist, reach, 65535))
+        lnib, lext = _length(0, ll)
+        mnib, mext = _length(4, ml)
+        comp += bytes([(lnib << 4) | mnib]) + lext + lits + bytes([dist & 255, dist >> 8]) + mext
+        out += lits
+        for _ in range(ml):  # byte_writer.dart:116-118
+            p = len(out) - dist
+            out.append(out[p] if p >= 0 else hist[len(hist) + p])
+        if end_after_match and len(out) >= target - 8 and len(out) > 0:
+            break
+    return bytes(comp), bytes(out)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_hand_built_linked_frames_decode_like_the_oracle(oracle, seed):
+    rng = random.Random(1000 + seed)
+    dictionary = rng.randbytes(rng.choice([0, 0, 100, 70000]))
+    history = bytearray(dictionary)
+    blocks = []
+    for b in range(rng.choice([4, 7, 12])):
+        if rng.random() < 0.15:  # a stored block between compressed ones
+            raw = rng.randbytes(rng.choice([1, 5000, 65536]))
+            blocks.append((raw, raw, True))
+            history += raw
+            continue
+        target = rng.choice([65536, 65536, 65536, 1, 17, 30000])
+        comp, dec = synthetic_block(rng, history, target, end_after_match=rng.random() < 0.3)
+        assert len(dec) <= 65536
+        blocks.append((comp, dec, False))
+        history += dec
+    flg = 0x40 | 0x04 | (0x01 if dictionary else 0)  # version 01, linked blocks, content checksum
+    frame = build_frame(flg, 0x40, blocks, oracle.xxh32, add_content_checksum=True, dict_id=5 if dictionary else None)
+    want = bytes(history[len(dictionary):])
+    kw = {"dictionaryResolver": (lambda i: dictionary)} if dictionary else {}
+    okw = {"dictionary_resolver": (lambda i: dictionary)} if dictionary else {}
+    assert oracle.frame_decode(frame, **okw) == want
+    fast, chain = decode_both(frame, require=len(blocks) >= 4, **kw)
+    assert fast == want and chain == want

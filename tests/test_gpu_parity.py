@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.helpers import GOLDEN_DIR, build_frame, corpus, corpus_block, golden, golden_frame, ramp, u32le
+from tests.helpers import (GOLDEN_DIR, block_of_sequences, build_frame, corpus, corpus_block, golden, golden_frame, ramp,
+                           u32le)
 
 pytestmark = pytest.mark.gpu
 
@@ -222,6 +223,55 @@ def test_block_decoder_fuzz_status_parity(codec, oracle, decode_form):
                 assert int(out_len[k]) == len(ref)
                 assert out[k, : len(ref)].tobytes() == ref
     assert N.OK == 0
+
+
+LENGTHS_LIT = [0, 0, 1, 3, 14, 15, 16, 40, 269, 270, 271, 300, 525, 1100, 1799, 1800, 2300, 4347, 4352, 5000]
+LENGTHS_MATCH = [4, 4, 5, 8, 18, 19, 20, 64, 273, 274, 275, 528, 529, 600, 1300, 1548, 1549, 4000]
+DISTANCES = [1, 2, 3, 7, 31, 64, 200, 255, 256, 4095, 4096, 65535]
+
+
+def test_block_decoder_hand_built_sequences(codec, oracle, decode_form):
+    """Blocks put together from sequences with any number of length-extension bytes, long matches in front of long
+    literal runs, overlapping matches and distances up to the window, strict and lenient (with a prefix), every
+    byte and every status against the oracle.  The first block is one that a batch once ended wrongly on: the list
+    of token starts leaves the real chain behind a match with three extension bytes, and the byte it lands on
+    parses as a token that a batch cannot take."""
+    import random
+
+    import torch
+    rng = random.Random(77)
+    cases = [[(300, 4, 1), (0, 274, 200), (40, 600, 200), (16, 273, 64), (0, 1300, 200), (40, 274, 200), (4352, 18, 300)]]
+    for _ in range(150):
+        n = rng.choice([2, 5, 9, 30])
+        seqs = [(rng.choice([5, 40, 300]), 4, 1)]
+        seqs += [(rng.choice(LENGTHS_LIT), rng.choice(LENGTHS_MATCH), rng.choice(DISTANCES + [rng.randrange(1, 65536)]))
+                 for _ in range(n)]
+        if rng.random() < 0.7:
+            seqs.append((rng.choice([1, 7, 5000]), 0, 0))  # (an empty last run is trailing bytes for the strict decoder)
+        cases.append(seqs)
+    for prefix in (b"", rng.randbytes(65536), rng.randbytes(300)):
+        built = [block_of_sequences(c, rng, prefix) for c in cases]
+        built = [(c, o) for c, o in built if len(o) <= 262144]
+        slot = 262144
+        offs, blob = [], bytearray()
+        for c, _ in built:
+            offs.append(len(blob))
+            blob += c
+        blob += bytes(64)
+        comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+        sizes = torch.tensor([len(c) for c, _ in built], dtype=torch.int32, device="cuda")
+        offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+        expected = torch.tensor([len(o) for _, o in built], dtype=torch.int32, device="cuda")
+        d = torch.tensor(np.frombuffer(prefix, dtype=np.uint8).copy(), device="cuda") if prefix else None
+        for strict in ((True, False) if not prefix else (False,)):
+            out, out_len, status = codec.decompress_blocks(comp, sizes, slot, comp_offsets=offsets, expected=expected,
+                                                           strict=strict, dictionary=d)
+            out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+            for k, (c, o) in enumerate(built):
+                ref = oracle.block_decompress(c, len(o)) if strict else oracle.block_decompress_into(c, prefix, len(prefix) + len(o))[len(prefix):]
+                assert ref == o
+                assert int(status[k]) == 0 and int(out_len[k]) == len(o), (len(prefix), strict, k, cases[k][:8])
+                assert out[k, : len(o)].tobytes() == o, (len(prefix), strict, k, cases[k][:8])
 
 
 def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle, decode_form):
