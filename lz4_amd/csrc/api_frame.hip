@@ -440,10 +440,10 @@ static int link_resolve_mode() {
 }
 
 // Sizes of all blocks (h_olen, h_stat), then chunk by chunk: literals and distances, doubling rounds until no
-// distance moves, the copied bytes.  h_word: a pinned word for the "something moved" read-back.  *resolved = false when a block is not for this path (the output buffer may
+// distance moves, the copied bytes.  limit_total: what the caller's buffer and output limit allow.  h_word: a pinned word for the "something moved" read-back.  *resolved = false when a block is not for this path (the output buffer may
 // hold partial data then; the chain writes all of it again).
-static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_t *d_dict, uint32_t *h_olen,
-                            int32_t *h_stat, uint32_t *h_word, bool *resolved) {
+static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_t *d_dict, uint64_t limit_total,
+                            uint32_t *h_olen, int32_t *h_stat, uint32_t *h_word, bool *resolved) {
   *resolved = false;
   const uint64_t slot = la.block_max;
   la.first = 0;
@@ -457,6 +457,7 @@ static int32_t link_resolve(lz4mi_ctx *c, LinkArgs la, uint32_t nb, const uint8_
     if (h_stat[b] != 0 || h_olen[b] > slot) return LZ4MI_OK;
     total += h_olen[b];
   }
+  if (total > limit_total) return LZ4MI_OK;  // the caller's buffer or output limit ends inside the frame: the chain reports it
   // scratch: block offsets, tile flags and the moved word, the distance array of the largest chunk
   const uint64_t chunk_bytes = link_chunk_bytes();
   uint64_t chunk_cap = 0, run = 0;
@@ -653,7 +654,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
   };
 
   bool resolved = false;
-  if (!indep && nb >= kLinkMinBlocks && (uint64_t)nb * slot <= limit_total + slot && link_resolve_mode() != 0) {
+  if (!indep && nb >= kLinkMinBlocks && link_resolve_mode() != 0) {
     // linked blocks, every block at once (decode_linked_kernel.hip); anything but a well-formed frame that fits
     // the limits is left to the chain below
     LinkArgs la;
@@ -666,7 +667,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
     la.dict_len = (uint32_t)(d_dict ? dict_len : 0);
     la.out_len = d_olen;
     la.status = d_stat;
-    st = link_resolve(c, la, nb, d_dict, h_olen, h_stat, (uint32_t *)((uint8_t *)c->h_pin + hb + 32), &resolved);
+    st = link_resolve(c, la, nb, d_dict, limit_total, h_olen, h_stat, (uint32_t *)((uint8_t *)c->h_pin + hb + 32), &resolved);
     if (st) return st;
     if (resolved) {
       for (uint32_t b = 0; b < nb; b++)
