@@ -848,9 +848,12 @@ typedef const volatile __attribute__((address_space(4))) EncodeKArgs *EncodeKArg
 #define LZ4MI_ENC_WPW 4
 #endif
 constexpr uint32_t kEncWpw = LZ4MI_ENC_WPW;  // wavefronts per workgroup
+#ifndef LZ4MI_ENC_WPE
+#define LZ4MI_ENC_WPE 4  // resident wavefronts per SIMD the register budget is set for (with the ring, sixteen per CU)
+#endif
 
 template <bool HAS_DICT, bool LINKED, bool WIDE = false, bool TAG = false>
-__global__ __launch_bounds__(64 * kEncWpw) __attribute__((amdgpu_waves_per_eu(4, 4))) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
+__global__ __launch_bounds__(64 * kEncWpw) __attribute__((amdgpu_waves_per_eu(LZ4MI_ENC_WPE, LZ4MI_ENC_WPE))) void encode_fast_kernel(BatchArgs, uint32_t, EncodeScratch, uint32_t *) {
   __shared__ __attribute__((aligned(16))) uint8_t s_win[kEncWpw][kWinBytes + kWinPad];
   __shared__ uint32_t s_claim[kEncWpw][kClaimSlots];
   EncodeKArgsPtr ka = (EncodeKArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
