@@ -414,9 +414,16 @@ int32_t host_copy(lz4mi_ctx *c, void *dst, const void *src, size_t n, hipMemcpyK
     err[k] = e;
   };
   std::thread helpers[kThreads - 1];
-  for (unsigned k = 1; k < kThreads; k++) helpers[k - 1] = std::thread(part, k);
+  for (unsigned k = 1; k < kThreads; k++) {
+    try {
+      helpers[k - 1] = std::thread(part, k);
+    } catch (...) {  // no thread to be had: this slice goes with the calling thread's
+      part(k);
+    }
+  }
   part(0);
-  for (std::thread &t : helpers) t.join();
+  for (std::thread &t : helpers)
+    if (t.joinable()) t.join();
   for (unsigned k = 0; k < kThreads; k++) LZ4MI_HIP(c, err[k]);
   return LZ4MI_OK;
 }
