@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <future>
 #include <string>
 #include <vector>
 
@@ -130,6 +131,20 @@ int32_t run_decompress(lz4mi_ctx *c, const BatchArgs &a, bool strict);
 int32_t pin_reserve(lz4mi_ctx *c, size_t n);
 // makes the side stream and its two events
 int32_t side_stream_ready(lz4mi_ctx *c);
+
+// f() on a thread of its own, beside the caller's GPU work; on the calling thread when no thread is to be had
+// (the future then holds the finished result).  Nothing is thrown across the C ABI.
+template <class F>
+auto run_beside(F f) -> std::future<decltype(f())> {
+  try {
+    return std::async(std::launch::async, f);
+  } catch (...) {
+    std::packaged_task<decltype(f())()> task(f);
+    auto fut = task.get_future();
+    task();
+    return fut;
+  }
+}
 
 // Bulk copy between the caller's host memory and the device: a device-to-host copy first waits for the context's
 // stream and returns when the bytes have arrived; a host-to-device copy returns when src may be reused and is

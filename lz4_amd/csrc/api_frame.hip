@@ -268,7 +268,7 @@ static int32_t frame_encode_device_impl(lz4mi_ctx *c, const uint8_t *d_src, uint
     LZ4MI_HIP(c, hipEventRecord(c->side_fork, c->stream));  // whatever produced d_src on this stream is done
     LZ4MI_HIP(c, hipStreamWaitEvent(c->side_stream, c->side_fork, 0));
     hipError_t *ep = &via_host_err;
-    via_host = std::async(std::launch::async, [c, d_src, n, ep] {
+    via_host = run_beside([c, d_src, n, ep] {
       uint32_t h = 0;
       *ep = xxh32_device_on_host(c, d_src, n, 0, &h);
       return h;
@@ -333,7 +333,7 @@ extern "C" int32_t lz4mi_frame_encode(lz4mi_ctx *c, const uint8_t *src, size_t n
   // The source is host memory: its content checksum (one serial chain of rounds, :148,163,266) runs on a host
   // thread while the GPU compresses the blocks.  The future's destructor joins the thread on every return path.
   std::future<uint32_t> content_hash;
-  if (o->content_checksum) content_hash = std::async(std::launch::async, [src, n] { return xxh32_host(src, n); });
+  if (o->content_checksum) content_hash = run_beside([src, n] { return xxh32_host(src, n); });
   const size_t fb = lz4mi_frame_bound(n, o);
   LZ4MI_HIP(c, c->in.ensure(n + 16));
   LZ4MI_HIP(c, c->out.ensure(fb + 16));
@@ -811,7 +811,7 @@ int32_t decode_blocks(lz4mi_ctx *c, const uint8_t *region, size_t region_len, co
       if (e == hipSuccess) {
         lz4mi_xxh32_state *hp = &hs;
         const uint8_t *q = dst + off;
-        hashing = std::async(std::launch::async, [hp, q, m] { xxh_state_update_host(hp, q, m); });
+        hashing = run_beside([hp, q, m] { xxh_state_update_host(hp, q, m); });
       }
     }
     if (hashing.valid()) hashing.get();

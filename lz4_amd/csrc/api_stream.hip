@@ -409,7 +409,7 @@ extern "C" int32_t lz4mi_frame_encoder_update(lz4mi_frame_encoder *e, const uint
   } hashing;
   if (e->o.content_checksum) {
     lz4mi_xxh32_state *hs = &e->hasher;
-    if (n >= (256u << 10)) hashing.f = std::async(std::launch::async, [hs, chunk, n] { xxh_state_update_host(hs, chunk, n); });
+    if (n >= (256u << 10)) hashing.f = run_beside([hs, chunk, n] { xxh_state_update_host(hs, chunk, n); });
     else xxh_state_update_host(hs, chunk, n);
   }
   e->pending += n;
