@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Callable, Optional
 
+import numpy as np
+
 from . import _native as N
 from .exceptions import Lz4Exception, RangeError
 from .options import (Lz4CompressionLevel, Lz4FrameBlockSize, Lz4FrameCompression, Lz4FrameOptions,
@@ -112,13 +114,14 @@ def lz4FrameEncodeWithOptions(src, *, options: Lz4FrameOptions, dictionary=None,
     L = N.load()
     o = _c_options(options)
     cap = L.lz4mi_frame_bound(len(src), C.byref(o))
-    dst = C.create_string_buffer(cap)
+    dst = np.empty(max(cap, 1), dtype=np.uint8)  # not zero-filled: its pages are first touched by the copy threads
     out = C.c_size_t(0)
     d = bytes(dictionary) if dictionary is not None else None
-    st = L.lz4mi_frame_encode(ctx.handle, src, len(src), C.byref(o), d, len(d) if d else 0, dst, cap, C.byref(out))
+    st = L.lz4mi_frame_encode(ctx.handle, src, len(src), C.byref(o), d, len(d) if d else 0,
+                              C.c_void_p(dst.ctypes.data), cap, C.byref(out))
     if st:
         N.raise_status(st, ctx.handle)
-    return C.string_at(dst, out.value)  # one copy of the frame, not of the whole bound
+    return dst[:out.value].tobytes()  # one copy of the frame, not of the whole bound
 
 
 def lz4FrameEncode(src, *, acceleration: int = 1, dictionary=None, device=None) -> bytes:  # noqa: N802
@@ -146,14 +149,14 @@ def lz4FrameDecode(src, *, maxOutputBytes: int | None = None,  # noqa: N802,N803
         L.lz4mi_frame_decode_bound(C.c_void_p(addr + pos), len(src) - pos, C.byref(bound))
         remaining = -1 if maxOutputBytes is None else maxOutputBytes - produced_total
         cap = bound.value if remaining < 0 else min(bound.value, remaining + 1)
-        dst = C.create_string_buffer(max(cap, 1))
+        dst = np.empty(max(cap, 1), dtype=np.uint8)  # not zero-filled
         consumed, produced, need = C.c_size_t(0), C.c_size_t(0), C.c_uint32(0)
         state = 0
         frame_dict = dict_bytes
         while True:
             st = L.lz4mi_frame_decode_next(ctx.handle, C.c_void_p(addr + pos), len(src) - pos, C.byref(consumed),
                                            frame_dict, len(frame_dict) if frame_dict else 0, state,
-                                           int(dict_bytes is not None), remaining, dst, cap,
+                                           int(dict_bytes is not None), remaining, C.c_void_p(dst.ctypes.data), cap,
                                            C.byref(produced), C.byref(need))
             if st == N.NEED_DICT and state == 0:
                 if dictionaryResolver is None:
@@ -171,7 +174,7 @@ def lz4FrameDecode(src, *, maxOutputBytes: int | None = None,  # noqa: N802,N803
             N.raise_status(st, ctx.handle, dict_id=need.value)
         if state == 1:
             dict_bytes = frame_dict
-        parts.append(C.string_at(dst, produced.value))
+        parts.append(dst[:produced.value].tobytes())
         produced_total += produced.value
         pos += consumed.value
     return parts[0] if len(parts) == 1 else b"".join(parts)
