@@ -29,6 +29,6 @@ for arg in sys.argv[1:] or ['5']:
     for role, title in ((0, 'parsing wavefront'), (1, 'copying wavefront')):
         print(f'  {title}')
         for i, nm in enumerate(names):
-            x = v[16 * role + i]
+            x = v[32 * role + i]  # PH_SLOTS per wavefront
             if x:
                 print(f'   {nm:34s} {x / NB / 1000:10.1f} kcycles per block')
