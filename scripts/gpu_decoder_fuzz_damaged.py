@@ -21,13 +21,14 @@ t0 = time.time()
 SLOT = 65536
 for rnd in range(rounds):
     rng = random.Random(seed0 * 1000 + rnd)
+    PRE = rng.randbytes(65536) if rnd % 3 == 2 else b""
     cases = []
     while len(cases) < 400:
         n = rng.choice([1, 3, 9, 30])
         seqs = [(rng.choice([1, 5, 40]), 4, 1)] + [(rng.choice(LIT), rng.choice(MAT), rng.choice(DST)) for _ in range(n)]
         if rng.random() < 0.7:
             seqs.append((rng.choice([1, 7, 300]), 0, 0))
-        c, o = block_of_sequences(seqs, rng)
+        c, o = block_of_sequences(seqs, rng, PRE)
         if not 0 < len(o) <= SLOT - 8:
             continue
         for _ in range(4):
@@ -51,18 +52,20 @@ for rnd in range(rounds):
     sizes = torch.tensor([len(c) for c, _ in cases], dtype=torch.int32, device="cuda")
     offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
     expected = torch.tensor([z for _, z in cases], dtype=torch.int32, device="cuda")
-    for strict in (True, False):
+    pre = PRE  # every third round: lenient decode behind a prefix that the matches reach into
+    d = torch.tensor(np.frombuffer(pre, dtype=np.uint8).copy(), device="cuda") if pre else None
+    for strict in ((True, False) if not pre else (False,)):
         def ref_of(k):
             c, z = cases[k]
             try:
-                return (0, oracle.block_decompress(c, z) if strict else oracle.block_decompress_into(c, b"", z))
+                return (0, oracle.block_decompress(c, z) if strict else oracle.block_decompress_into(c, pre, len(pre) + z)[len(pre):])
             except oracle.Lz4RefError as e:
                 return (e.status, None)
         with ThreadPoolExecutor(16) as ex:
             refs = list(ex.map(ref_of, range(len(cases))))
         for form in (1, 2):
             L.lz4mi_ctx_set_decode_form(codec.ctx.handle, form)
-            out, out_len, status = codec.decompress_blocks(comp, sizes, SLOT, comp_offsets=offsets, expected=expected, strict=strict)
+            out, out_len, status = codec.decompress_blocks(comp, sizes, SLOT, comp_offsets=offsets, expected=expected, strict=strict, dictionary=d)
             out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
             for k, (rs, rb) in enumerate(refs):
                 ok = int(status[k]) == rs and (rb is None or (int(out_len[k]) == len(rb) and out[k, :len(rb)].tobytes() == rb))
