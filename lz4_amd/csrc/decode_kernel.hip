@@ -462,6 +462,15 @@ __device__ __forceinline__ int32_t decode_run(const uint8_t *__restrict__ src, u
 #ifndef LZ4MI_BATCH
 #define LZ4MI_BATCH 3584
 #endif
+#ifndef LZ4MI_DEC_WPE
+#define LZ4MI_DEC_WPE 4  // resident wavefronts per SIMD the decode kernels are compiled for (register budget 512 / this)
+#endif
+#ifndef LZ4MI_PAIR_WPE
+#define LZ4MI_PAIR_WPE 4
+#endif
+#ifndef LZ4MI_DEC_ATTR
+#define LZ4MI_DEC_ATTR
+#endif
 constexpr uint32_t kH = LZ4MI_HIST;         // output bytes kept in LDS in front of a batch (multiple of 1024)
 constexpr uint32_t kBatchOut = LZ4MI_BATCH; // most output bytes of one batch
 constexpr uint32_t kStgBytes = kH + 16 + kBatchOut + 16;  // staging buffer of a wavefront on its own: history, alignment slack, batch, store slack
@@ -878,57 +887,37 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
 // linked block near its start, has most of its matches here: the round trips are what that costs.)
 constexpr uint32_t kFarPieces = 16;
 #ifndef LZ4MI_FAR_SHORT
-#define LZ4MI_FAR_SHORT 1
-#endif
-#ifndef LZ4MI_FAR_SLOT
-#define LZ4MI_FAR_SLOT 16
+#define LZ4MI_FAR_SHORT 1  // 0: every out-of-buffer match goes through the pieces (A/B builds)
 #endif
 template <bool HAS_PREFIX, uint32_t D>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
                                          uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
   uint64_t fm = ballot(q.far);
   if (!fm) return;
-  // Short matches (text-like data through a strong encoder: seven bytes per match at distances all over the
-  // block, so most of them are out of the buffer) would each take a piece of 64 lanes below.  They go four to a
-  // load instead, sixteen lanes per match (eight and thirty-two lanes per match measured slower), eight loads in
-  // flight: 32 matches per round trip where the pieces took two round trips.  The short matches are first
-  // packed into the low lanes (lane k: the k-th of them), then lane l of load r serves match 4 r + l / 16.
+  // Short matches (text-like data through a strong encoder: eight bytes per match at distances all over the
+  // block, so four of five are out of the buffer) would each take a piece of 64 lanes below.
+  // One lane per match instead: a single 16-byte load (any alignment) per lane brings every short match of the
+  // batch in one instruction and one round trip; the bytes behind a match's end are read and dropped (its source
+  // lies more than the history in front of the output, so they are inside the output buffer).  A source that
+  // touches the prefix's last 15 bytes would read past that buffer: it stays with the pieces below.
+  // (Issuing this load in front of the first round of pieces, so that a batch with both kinds waits for memory
+  // once, keeps six more registers alive across that loop and the kernel spills: measured twice as slow.)
   if (LZ4MI_FAR_SHORT) {
-    constexpr uint32_t S = LZ4MI_FAR_SLOT, PER = kWave / S;  // lanes per match, matches per load
-    const bool fs = q.far && q.ml <= S;
+    const int64_t ap = (int64_t)op_start + q.sp;
+    const bool fs = q.far && q.ml <= 16u && (!HAS_PREFIX || ap >= 0 || ap + 16 <= 0);
     const uint64_t sm = ballot(fs);
-    const uint32_t ns = (uint32_t)__builtin_popcountll(sm);
-    if (ns >= 4u) {
-      // forward permute: a lane that holds no short match sends to lane 63, which holds a packed entry only
-      // when all 64 lanes are short matches (and then nobody else sends there)
-      const int to = (int)(4u * (fs ? mbcnt64(sm) : 63u));
-      const uint32_t c_sp = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)q.sp);
-      const uint32_t c_dl = (uint32_t)__builtin_amdgcn_ds_permute(to, (int)((q.o_mat + sneg) | (q.ml << 16)));
-      const uint32_t g = lane / S, t = lane % S;
-      for (uint32_t k0 = 0; k0 < ns; k0 += 8u * PER) {  // eight loads in flight
-        uint32_t v[8];
+    if ((uint32_t)__builtin_popcountll(sm) >= 4u) {
+      typedef u32x4 u32x4_any __attribute__((aligned(1)));
+      typedef __attribute__((address_space(1))) u32x4_any g_v4any;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (fs) v = *(const g_v4any *)((HAS_PREFIX && ap < 0) ? prefix + ((int64_t)prefix_len + ap) : dst + ap);
+      const uint32_t d0 = q.o_mat + sneg, n = fs ? q.ml : 0u;
 #pragma unroll
-        for (uint32_t r = 0; r < 8; r++) {
-          v[r] = 0;
-          if (k0 + PER * r < ns) {
-            const int from = (int)(4u * (k0 + PER * r + g));
-            const int32_t sp = __builtin_amdgcn_ds_bpermute(from, (int)c_sp);
-            const uint32_t ml = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)c_dl) >> 16;
-            if (k0 + PER * r + g < ns) {  // lanes past the end of a match read its last byte again
-              const int64_t ap = (int64_t)op_start + sp + (int64_t)(t < ml ? t : ml - 1u);
-              v[r] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
-            }
-          }
-        }
-#pragma unroll
-        for (uint32_t r = 0; r < 8; r++) {
-          if (k0 + PER * r < ns) {
-            const uint32_t dl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(4u * (k0 + PER * r + g)), (int)c_dl);
-            stg[k0 + PER * r + g < ns && t < (dl >> 16) ? (dl & 0xffffu) + t : D + lane] = (uint8_t)v[r];
-          }
-        }
-        vm_quiesce();
+      for (uint32_t t = 0; t < 16u; t++) {
+        if ((t == 8u || t == 12u) && !ballot(t < n)) break;
+        stg[t < n ? d0 + t : D + lane] = (uint8_t)(v[t >> 2] >> (8u * (t & 3u)));
       }
+      vm_quiesce();
       fm &= ~sm;
       if (!fm) return;
     }
@@ -987,7 +976,11 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   const bool ovl = q.dist < q.ml;
   const uint32_t m_src = ((uint32_t)q.sp + sneg) & 0xffffu, m_dst = q.o_mat + sneg;
   const uint32_t m_len = q.far ? 0u : q.ml, m_per = ovl ? q.dist : 0xffffu;
-  const uint32_t m_mg = ovl ? 65536u / q.dist + 1u : 0u, m_step = ovl ? 64u % q.dist : kWave;
+  uint32_t m_mg = 0u, m_step = kWave;
+  if (ovl) {  // the two divisions only where a lane has such a match (text-like data: hardly ever)
+    m_mg = 65536u / q.dist + 1u;
+    m_step = 64u % q.dist;
+  }
   // Short matches out of the history: a match of at most sixteen bytes whose source ends in front of the batch's
   // first output byte reads nothing that this batch writes, so all of them are copied first, packed four to an
   // LDS operation (sixteen lanes per match, as the out-of-buffer loads are), every read of a round queued before
@@ -1415,7 +1408,7 @@ __device__ __forceinline__ BlockState block_start(const uint8_t *out) {
 // offers its help, and the other one, between two batches of its last block, takes it.  From there on the two share
 // that block as decode_block_pair does, in the two buffers taken together.
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(LZ4MI_DEC_WPE, LZ4MI_DEC_WPE))) LZ4MI_DEC_ATTR void decode_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stg[2][kStgAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[2][kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) uint16_t s_tl[2][kTl];
@@ -1534,7 +1527,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // One workgroup of two wavefronts per block: the form for launches that leave wavefront slots empty (a block is
 // done in 0.6 of the time a wavefront on its own takes, but a CU holds eight such blocks instead of sixteen).
 template <bool STRICT, bool HAS_PREFIX>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void decode_pair_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(LZ4MI_PAIR_WPE, LZ4MI_PAIR_WPE))) LZ4MI_DEC_ATTR void decode_pair_kernel(BatchArgs a, uint32_t *counter, const uint32_t *order) {
   __shared__ __attribute__((aligned(16))) uint8_t s_stg[kStgPairAlloc];
   __shared__ __attribute__((aligned(16))) uint8_t s_cw[kCw + kCwPad];
   __shared__ __attribute__((aligned(16))) uint16_t s_tl[kTl];

@@ -116,6 +116,9 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 // A function of its own, not inlined: its twelve 16-byte registers per lane would otherwise count against every
 // kernel that copies anything.  (What is left behind the last 12 KiB goes through wave_copy: taking it in one
 // predicated round trip here as well measured slower, bench decode launch 0.462 -> 0.473 ms.)
+#ifndef LZ4MI_COPY_LONG_K
+#define LZ4MI_COPY_LONG_K 12  // 16-byte registers per lane: KiB in flight per round trip
+#endif
 __device__ __attribute__((noinline)) void wave_copy_long(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane) {
   // Both ranges are device memory: global pointers, so that the loop is global_load / global_store (through the
   // generic pointers of a function that is not inlined it would be flat instructions, which count against the LDS
@@ -131,13 +134,14 @@ __device__ __attribute__((noinline)) void wave_copy_long(uint8_t *dst, const uin
   const g_u8 *gs = (const g_u8 *)s;
   g_u8 *gd = (g_u8 *)d;
   uint32_t off = 0;
-  for (; off + 12288 <= n - head; off += 12288) {
+  constexpr int K = LZ4MI_COPY_LONG_K;
+  for (; off + 1024 * K <= n - head; off += 1024 * K) {
     // streamed once: nontemporal on both sides (scripts/micro/copy_tp.hip: 5.3 against 5.1 TB/s chip-wide)
-    u32x4 v[12];
+    u32x4 v[K];
 #pragma unroll
-    for (int k = 0; k < 12; k++) v[k] = __builtin_nontemporal_load((const g_v4any *)(gs + off + 16 * lane + 1024 * k));
+    for (int k = 0; k < K; k++) v[k] = __builtin_nontemporal_load((const g_v4any *)(gs + off + 16 * lane + 1024 * k));
 #pragma unroll
-    for (int k = 0; k < 12; k++) __builtin_nontemporal_store(v[k], (g_v4 *)(gd + off + 16 * lane + 1024 * k));
+    for (int k = 0; k < K; k++) __builtin_nontemporal_store(v[k], (g_v4 *)(gd + off + 16 * lane + 1024 * k));
   }
   wave_copy(d + off, s + off, n - head - off, lane);
 }
