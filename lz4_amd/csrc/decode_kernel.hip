@@ -490,6 +490,14 @@ constexpr uint32_t kSeqTyp = 320;           // a window with fewer bytes than th
 constexpr uint32_t kPrioT[3] = {LZ4MI_PRIO_T};  // compressed bytes left from which a block runs at issue priority 3, 2, 1
 constexpr uint32_t kPrio3 = kPrioT[0], kPrio2 = kPrioT[1], kPrio1 = kPrioT[2];
 constexpr uint32_t kHelpMin = 1024;         // compressed bytes left from which a block is worth a second wavefront
+#ifndef LZ4MI_PACKED_MIN
+#define LZ4MI_PACKED_MIN 10
+#endif
+#ifndef LZ4MI_PACKED_RUN
+#define LZ4MI_PACKED_RUN 2
+#endif
+constexpr uint32_t kPackedRun = LZ4MI_PACKED_RUN;  // ... in so many chunk steps in a row
+constexpr uint32_t kPackedMin = LZ4MI_PACKED_MIN;  // tokens per 64-byte chunk from which the four-chunk step is taken
 constexpr uint32_t kTl = 136;               // token list entries (two bytes each): 64 tokens, a spare, the dummy slot at 128
 static_assert(kLitMax + kMatMax <= kBatchOut && kSeqIn <= kCw, "a batch holds at least one sequence");
 static_assert(kStgBytes >= kRing, "the general loop uses the first kRing bytes of the staging buffer");
@@ -647,6 +655,7 @@ struct ParseCtx {      // what the parsing side keeps between batches
   bool have_win;
   bool dense;          // token chain: tokens are close together (chunk steps) or far apart (scalar steps)
   uint32_t shortrun;   // scalar steps in a row that were short
+  uint32_t packed;     // chunk steps in a row with so many tokens per chunk that four chunks at once pay (kPackedMin)
 };
 struct BatchPlan {     // wave-uniform
   uint32_t nb;         // sequences the batch takes
@@ -661,12 +670,100 @@ struct SeqLane {       // lane j: sequence j
   bool far;                   //        source older than the buffer: fetched from memory
 };
 
+// The token chain over four chunks (256 bytes) at once, without a walk from token to token: lane p of chunk c parses
+// byte a + 64 c + p as a token; its link says where the token behind it starts: four times the lane, if that is in
+// the same chunk, else the distance in lanes << 8 (the low byte is 0); a token that is not for the chain, or not
+// inside the window, carries (0x8000 | lane) << 8.  Pointer jumping finds every lane's way out of its chunk in five
+// rounds (a chunk holds at most 22 tokens), the four chunks side by side (every round issues its four cross-lane
+// reads before it uses the first: left to itself the scheduler keeps two in flight); the ways out give the lane at
+// which the chain enters each chunk, and five more rounds push a mark from there along the links of 1, 2, 4, 8 and
+// 16 tokens.  A lane without a mark, or whose link leads out, sends to lane 0, which no link names.  The list may
+// get more entries than a batch takes (they are found again by the next parse) and drops what does not fit.
+// Returns tokens found | bytes the chain moved on << 8 | (it ends in front of a token that is not for it) << 31.
+// A function of its own, not inlined: its twenty link registers stay out of the register allocation of the kernels'
+// other paths, and the kernels stay smaller by one copy per instantiation.
+__device__ __attribute__((noinline)) uint32_t chain_four_chunks(const lds_u8 *cw, lds_u16 *tl, uint32_t a, uint32_t wlim,
+                                                                  uint32_t count, uint32_t lane) {
+  constexpr uint32_t G = 4;
+  uint32_t Jk[5][G], J[G];
+#pragma unroll
+  for (uint32_t c = 0; c < G; c++) {
+    const uint32_t t4 = cw32(cw, a + 64u * c + lane);
+    const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
+    const bool isl = ll0 == 15u;
+    const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
+    const bool ok = a + 64u * c + nx <= wlim && !(isl && e1 == 255u);
+    J[c] = ok ? (nx < kWave ? 4u * nx : nx << 8) : (0x8000u | lane) << 8;
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < 5; k++) {
+    uint32_t j2[G];
+#pragma unroll
+    for (uint32_t c = 0; c < G; c++) {
+      Jk[k][c] = J[c];
+      j2[c] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)J[c], (int)J[c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (uint32_t c = 0; c < G; c++) J[c] = J[c] < 256u ? j2[c] : J[c];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the lane at which the chain enters each chunk (64: it passes over the chunk, or has ended), and where it ends
+  uint32_t ent[G], r_end = 0;
+  bool notok = false;
+  {
+    bool open = true;
+#pragma unroll
+    for (uint32_t c = 0; c < G; c++) {
+      ent[c] = kWave;
+      if (open && r_end < 64u * (c + 1u)) {
+        ent[c] = r_end - 64u * c;
+        const uint32_t x = rdlane(J[c], ent[c]) >> 8;
+        notok = (x & 0x8000u) != 0u;  // the chain ends in front of that token
+        r_end = 64u * c + (x & 0x7fffu);
+        open = !notok;
+      }
+    }
+  }
+  const uint32_t not0 = lane != 0u ? ~0u : 0u;
+  uint32_t R[G];
+#pragma unroll
+  for (uint32_t c = 0; c < G; c++) R[c] = lane == ent[c] ? ~0u : 0u;
+#pragma unroll
+  for (uint32_t k = 0; k < 5; k++) {
+    uint32_t got[G];
+#pragma unroll
+    for (uint32_t c = 0; c < G; c++) got[c] = (uint32_t)__builtin_amdgcn_ds_permute((int)(R[c] & Jk[k][c]), -1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (uint32_t c = 0; c < G; c++) R[c] |= got[c] & not0;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  uint32_t n = 0;
+#pragma unroll
+  for (uint32_t c = 0; c < G; c++) {
+    const uint64_t starts = ballot(R[c] != 0u && !(Jk[0][c] & 0x800000u));
+    const uint32_t at = count + n + mbcnt64(starts);
+    tl[((starts >> lane) & 1ull) && at < 2u * kWave ? at : 2u * kWave] = (uint16_t)(a + 64u * c + lane);
+    n += (uint32_t)__builtin_popcountll(starts);
+  }
+  return n | r_end << 8 | (notok ? 0x80000000u : 0u);
+}
+
 // lo = lowest output position the buffer holds when the batch is copied, fl = output in front of this
 // position is in memory by then.  BATCH = most output bytes of the batch.
 template <uint32_t BATCH>
 __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src, uint32_t in_end, uint32_t ip, uint32_t op,
                                                  uint32_t cap, uint32_t back_limit, int32_t lo, uint32_t fl, lds_u8 *cw,
                                                  lds_u16 *tl, uint32_t lane, ParseCtx &pc, SeqLane &q) {
+#ifdef LZ4MI_PROFILE
+  PhState pps{ph_column(), __builtin_readcyclecounter()};  // slots 16..: where a parse spends its cycles
+#define PP(i) PHS(pps, i)
+#define PPC(i) do { pps.c[(i) * 64] += 1; } while (0)
+#else
+#define PP(i) do {} while (0)
+#define PPC(i) do {} while (0)
+#endif
   // ---- window: keep it while a typical sequence still fits behind ip, or it holds the block's end
   if (!pc.have_win || !((ip - (uint32_t)pc.wb) + kSeqTyp <= kCw || (uint32_t)(pc.wb + (int32_t)kCw) >= in_end)) {
     cw_load(cw, src, in_end, ip, lane, pc.wb, pc.wlim);
@@ -674,6 +771,7 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   }
   const int32_t wb = pc.wb;
   const uint32_t wlim = pc.wlim;
+  PP(16);
   // ---- chain of token starts.  Only where the tokens are is found here, under the assumption that no
   // match length has a second extension byte; the positions go into a list, lane j then reads sequence j
   // in full, and a sequence whose real successor is not the next position of the list ends the batch.
@@ -683,8 +781,23 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   uint32_t a = ip - (uint32_t)wb, count = 0, tot = 0;
   bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
   bool dense = pc.dense;
+  uint32_t packed = pc.packed;
   uint32_t shortrun = pc.shortrun;
   while (count < kWave && tot <= BATCH - 512u) {
+    if (dense && packed >= kPackedRun) {  // four chunks at once
+      const uint32_t res = uni(chain_four_chunks(cw, tl, a, wlim, count, lane));
+      const uint32_t n = res & 0xffu, r_end = (res >> 8) & 0x7fffffu;
+      const bool notok = (res >> 31) != 0u;
+      count += n;
+      count = count < 2u * kWave - 1u ? count : 2u * kWave - 1u;
+      tot += r_end + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
+      a += r_end;
+      dense = n >= 2u && !notok;
+      packed = n >= kPackedMin * 4u ? packed : 0u;
+      PP(17);
+      PPC(21);
+      continue;
+    }
     if (dense && count <= kWave - 22u) {
       const uint32_t t4 = cw32(cw, a + lane);
       const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
@@ -710,6 +823,9 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
       tot += r + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
       a += r;
       dense = n >= 2u && !notok;
+      packed = n >= kPackedMin ? packed + 1u : 0u;
+      PP(24);
+      PPC(25);
       continue;
     }
     // one token, in scalar registers
@@ -738,8 +854,13 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
     shortrun = nx - a < 24u ? shortrun + 1u : 0u;
     dense = shortrun >= 2u;
     a = nx;
+    PP(18);
+    PPC(22);
   }
+  PP(18);
+  PPC(23);
   pc.dense = dense;
+  pc.packed = packed;
   pc.shortrun = shortrun;
   BatchPlan bp;
   bp.nb = 0;
@@ -757,6 +878,7 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   const uint32_t ta = tl[lane], tn = tl[lane + 1u];
   const SeqFields g = seq_long(cw, ta, wlim);
   const uint32_t ll = mine ? g.ll : 0u, ml = mine ? g.ml : 0u, dist = g.dist;
+  PP(19);
   // the sequences in front of the first one that is not for the batch, or whose successor is not the
   // next token of the list, are real
   const uint64_t nokm = ballot(mine && !g.ok), brkm = ballot(mine && lane + 1u < count && g.nx != tn);
@@ -813,6 +935,7 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   q.ml = in ? ml : 0u;
   q.dist = dist ? dist : 1u;
   q.far = far && in;
+  PP(20);
   return bp;
 }
 
@@ -962,6 +1085,9 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
 // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
 // byte by byte: output byte k is byte k mod dist of the period in front of the match.
 // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
+#ifndef LZ4MI_TIMING_SKIP
+#define LZ4MI_TIMING_SKIP 0
+#endif
 #ifndef LZ4MI_NEAR_PACK
 #define LZ4MI_NEAR_PACK 1
 #endif
@@ -973,6 +1099,9 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   // is lane - ((lane * mg) >> 16) * dist with mg = 65536 / dist + 1 (off by less than 1 / dist for lane < 64),
   // and a piece of 64 bytes moves on by 64 mod dist.  A plain copy has mg = 0 (lane mod dist = lane where
   // it matters), step 64 and a period it never reaches.
+#if LZ4MI_TIMING_SKIP == 1
+  return;
+#endif
   const bool ovl = q.dist < q.ml;
   const uint32_t m_src = ((uint32_t)q.sp + sneg) & 0xffffu, m_dst = q.o_mat + sneg;
   const uint32_t m_len = q.far ? 0u : q.ml, m_per = ovl ? q.dist : 0xffffu;
@@ -987,7 +1116,7 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   // its writes.  What is left for the loop below keeps its order, and none of it reads a byte that such a match
   // writes later than the loop expects: a later match's output lies behind an earlier match's source.
   uint32_t m_todo = m_len;
-  if (LZ4MI_NEAR_PACK) {
+  if (LZ4MI_NEAR_PACK && LZ4MI_TIMING_SKIP != 2) {
     const bool pk = lane < nb && m_len != 0 && m_len <= 16u && !ovl &&
                     q.sp + (int32_t)q.ml <= (int32_t)rdlane(q.o_lit, 0);
     const uint64_t pm = ballot(pk);
@@ -1034,6 +1163,9 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   };
   // Most of the batch still to copy: count through it.  Few left (the rest was out of the buffer or went packed):
   // step from one to the next over a bit mask, which costs a little more per match and nothing per skipped one.
+#if LZ4MI_TIMING_SKIP == 3
+  return;
+#endif
   const uint64_t left0 = ballot(lane < nb && m_todo != 0);
   if (2u * (uint32_t)__builtin_popcountll(left0) > nb) {
     for (uint32_t j = 0; j < nb; j++) {

@@ -24,8 +24,12 @@ for rnd in range(rounds):
     PRE = rng.randbytes(65536) if rnd % 3 == 2 else b""
     cases = []
     while len(cases) < 400:
-        n = rng.choice([1, 3, 9, 30])
-        seqs = [(rng.choice([1, 5, 40]), 4, 1)] + [(rng.choice(LIT), rng.choice(MAT), rng.choice(DST)) for _ in range(n)]
+        if len(cases) % 16 < 4:  # token-dense blocks (hundreds of short sequences in a row)
+            n = rng.choice([60, 150, 400])
+            seqs = [(rng.choice([1, 5, 40]), 4, 1)] + [(rng.randrange(0, 4), rng.randrange(4, 21), rng.choice(DST)) for _ in range(n)]
+        else:
+            n = rng.choice([1, 3, 9, 30])
+            seqs = [(rng.choice([1, 5, 40]), 4, 1)] + [(rng.choice(LIT), rng.choice(MAT), rng.choice(DST)) for _ in range(n)]
         if rng.random() < 0.7:
             seqs.append((rng.choice([1, 7, 300]), 0, 0))
         c, o = block_of_sequences(seqs, rng, PRE)
