@@ -939,6 +939,11 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   return bp;
 }
 
+template <uint32_t N>
+struct UConst {
+  static constexpr uint32_t value = N;
+};
+
 // ---- literals: lane j copies the first 64 bytes of its run, window -> buffer.  No lane is ever masked
 // off (that costs more than the copies) and every LDS access is aligned (an unaligned one stalls the
 // LDS pipe of the CU): the up to three bytes in front of the first aligned dword of the destination
@@ -956,15 +961,29 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
   const uint32_t body = mid ? (n1 - head) >> 2 : 0u;  // aligned dwords, at most 16
   const uint32_t tail = mid ? (n1 - head) & 3u : 0u;
   {
+    // as many dwords per lane as the longest run of the batch needs, in steps (text-like data through a strong
+    // encoder has a byte or two of literals per sequence: most batches need none or two)
     const uint32_t sb = lsx + head, sh = sb & 3u;
     const lds_u32 *p = (const lds_u32 *)(cw + ((sb < kCwTop ? sb : kCwTop) & ~3u));
-    uint32_t wd[17];
-#pragma unroll
-    for (uint32_t k = 0; k < 17; k++) wd[k] = p[k];
     lds_u32 *d = (lds_u32 *)(stg + d0 + head);
     lds_u32 *dummy = (lds_u32 *)(stg + D + 64u);
+    const auto dwords = [&](auto kc) __attribute__((always_inline)) {
+      constexpr uint32_t K = decltype(kc)::value;
+      uint32_t wd[K + 1];
 #pragma unroll
-    for (uint32_t k = 0; k < 16; k++) *(k < body ? d + k : dummy) = __builtin_amdgcn_alignbyte(wd[k + 1], wd[k], sh);
+      for (uint32_t k = 0; k <= K; k++) wd[k] = p[k];
+#pragma unroll
+      for (uint32_t k = 0; k < K; k++) *(k < body ? d + k : dummy) = __builtin_amdgcn_alignbyte(wd[k + 1], wd[k], sh);
+    };
+    if (!ballot(body > 2u)) {
+      if (ballot(body > 0u)) dwords(UConst<2>{});
+    } else if (!ballot(body > 4u)) {
+      dwords(UConst<4>{});
+    } else if (!ballot(body > 8u)) {
+      dwords(UConst<8>{});
+    } else {
+      dwords(UConst<16>{});
+    }
   }
   {
     // six single bytes: head (or the whole of a short run) from the run's first bytes, tail from its last
@@ -1085,9 +1104,6 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
 // match reads whatever earlier matches and the literals wrote.  byte_writer.dart:116-118 copies
 // byte by byte: output byte k is byte k mod dist of the period in front of the match.
 // A match is copied in pieces of up to 64 bytes, a byte per lane; lanes past the end write to a dummy slot.
-#ifndef LZ4MI_TIMING_SKIP
-#define LZ4MI_TIMING_SKIP 0
-#endif
 #ifndef LZ4MI_NEAR_PACK
 #define LZ4MI_NEAR_PACK 1
 #endif
@@ -1099,9 +1115,6 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   // is lane - ((lane * mg) >> 16) * dist with mg = 65536 / dist + 1 (off by less than 1 / dist for lane < 64),
   // and a piece of 64 bytes moves on by 64 mod dist.  A plain copy has mg = 0 (lane mod dist = lane where
   // it matters), step 64 and a period it never reaches.
-#if LZ4MI_TIMING_SKIP == 1
-  return;
-#endif
   const bool ovl = q.dist < q.ml;
   const uint32_t m_src = ((uint32_t)q.sp + sneg) & 0xffffu, m_dst = q.o_mat + sneg;
   const uint32_t m_len = q.far ? 0u : q.ml, m_per = ovl ? q.dist : 0xffffu;
@@ -1116,7 +1129,7 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   // its writes.  What is left for the loop below keeps its order, and none of it reads a byte that such a match
   // writes later than the loop expects: a later match's output lies behind an earlier match's source.
   uint32_t m_todo = m_len;
-  if (LZ4MI_NEAR_PACK && LZ4MI_TIMING_SKIP != 2) {
+  if (LZ4MI_NEAR_PACK) {
     const bool pk = lane < nb && m_len != 0 && m_len <= 16u && !ovl &&
                     q.sp + (int32_t)q.ml <= (int32_t)rdlane(q.o_lit, 0);
     const uint64_t pm = ballot(pk);
@@ -1150,9 +1163,17 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
       if (pk) m_todo = 0;
     }
   }
-  const auto one = [&](uint32_t j, uint32_t m) __attribute__((always_inline)) {
-    const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
+  // A match of at most 64 bytes that does not overlap its source (nearly every match of text-like data) is one read
+  // and one write; bit 31 of the length marks the others (a period to repeat, or more than one piece).
+  const auto one = [&](uint32_t j, uint32_t mf) __attribute__((always_inline)) {
     const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
+    if (!(mf >> 31)) {
+      const uint32_t v = stg[ms + lane];
+      stg[lane < mf ? md : D + lane] = (uint8_t)v;
+      return;
+    }
+    const uint32_t m = mf & 0x7fffffffu;
+    const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
     uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
     for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
       const uint32_t v = stg[ms + r];
@@ -1161,16 +1182,14 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
       r = r >= per ? r - per : r;
     }
   };
+  m_todo |= (ovl || m_todo > kWave) ? 0x80000000u : 0u;
   // Most of the batch still to copy: count through it.  Few left (the rest was out of the buffer or went packed):
   // step from one to the next over a bit mask, which costs a little more per match and nothing per skipped one.
-#if LZ4MI_TIMING_SKIP == 3
-  return;
-#endif
-  const uint64_t left0 = ballot(lane < nb && m_todo != 0);
+  const uint64_t left0 = ballot(lane < nb && (m_todo & 0x7fffffffu) != 0u);
   if (2u * (uint32_t)__builtin_popcountll(left0) > nb) {
     for (uint32_t j = 0; j < nb; j++) {
       const uint32_t m = rdlane(m_todo, j);
-      if (m) one(j, m);
+      if (m & 0x7fffffffu) one(j, m);
     }
   } else {
     for (uint64_t left = left0; left; left &= left - 1ull) {
