@@ -493,6 +493,10 @@ constexpr uint32_t kHelpMin = 1024;         // compressed bytes left from which 
 #ifndef LZ4MI_PACKED_MIN
 #define LZ4MI_PACKED_MIN 10
 #endif
+#ifndef LZ4MI_WALK_CHUNKS
+#define LZ4MI_WALK_CHUNKS 2
+#endif
+constexpr uint32_t kWalk = LZ4MI_WALK_CHUNKS;  // 64-byte chunks per step of the token walk
 #ifndef LZ4MI_PACKED_RUN
 #define LZ4MI_PACKED_RUN 2
 #endif
@@ -799,31 +803,46 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
       continue;
     }
     if (dense && count <= kWave - 22u) {
-      const uint32_t t4 = cw32(cw, a + lane);
-      const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
-      const bool isl = ll0 == 15u;
-      const uint32_t nx = lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
-      // where the token behind this one starts; a token that is not for the chain (or not inside the window)
-      // points past every lane and carries its own lane, so the walk is one cross-lane read and one test per token
-      const uint32_t link = (a + nx <= wlim && !(isl && e1 == 255u)) ? nx : 0x8000u | lane;
-      uint64_t starts = 0;
-      uint32_t r = 0;
-      do {
-        starts |= 1ull << r;
-        r = rdlane(link, r);
-      } while (r < kWave);
-      const bool notok = (r & 0x8000u) != 0u;
-      if (notok) {  // the chain ends in front of that token
-        r &= 0x7fffu;
-        starts &= ~(1ull << r);
+      // kWalk chunks per step: lane p parses bytes a + 64 c + p as tokens, and the real starts are followed
+      // from token to token through all of them (one LDS round trip and one set-up for that many bytes; where
+      // tokens are far apart that is most of a step).  link = where the token behind this one starts, counted from
+      // a; a token that is not for the chain (or not inside the window) points past every lane and carries its own
+      // place, so the walk is one cross-lane read and one test per token.
+      uint32_t link[kWalk];
+#pragma unroll
+      for (uint32_t c = 0; c < kWalk; c++) {
+        const uint32_t t4 = cw32(cw, a + 64u * c + lane);
+        const uint32_t ll0 = (t4 >> 4) & 15u, e1 = (t4 >> 8) & 255u;
+        const bool isl = ll0 == 15u;
+        const uint32_t nx = 64u * c + lane + 3u + (isl ? 1u + e1 : 0u) + ll0 + ((t4 & 15u) == 15u ? 1u : 0u);
+        link[c] = (a + nx <= wlim && !(isl && e1 == 255u)) ? nx : 0x8000u | (64u * c + lane);
       }
-      tl[(starts >> lane) & 1ull ? count + mbcnt64(starts) : 2u * kWave] = (uint16_t)(a + lane);
-      const uint32_t n = (uint32_t)__builtin_popcountll(starts);
+      uint64_t starts[kWalk];
+      uint32_t r = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < kWalk; c++) {
+        starts[c] = 0;
+        while (r < 64u * (c + 1u)) {  // (the first token is at lane 0 of chunk 0)
+          starts[c] |= 1ull << (r - 64u * c);
+          r = rdlane(link[c], r - 64u * c);
+        }
+      }
+      const bool notok = (r & 0x8000u) != 0u;
+      if (notok) r &= 0x7fffu;  // the chain ends in front of that token
+      uint32_t n = 0;
+#pragma unroll
+      for (uint32_t c = 0; c < kWalk; c++) {
+        if (notok && r - 64u * c < kWave) starts[c] &= ~(1ull << (r - 64u * c));
+        const uint32_t at = count + n + mbcnt64(starts[c]);
+        tl[((starts[c] >> lane) & 1ull) && at < 2u * kWave ? at : 2u * kWave] = (uint16_t)(a + 64u * c + lane);
+        n += (uint32_t)__builtin_popcountll(starts[c]);
+      }
       count += n;
+      count = count < 2u * kWave - 1u ? count : 2u * kWave - 1u;
       tot += r + 64u * n;  // compressed bytes stand for the literals, a guess for the matches
       a += r;
       dense = n >= 2u && !notok;
-      packed = n >= kPackedMin ? packed + 1u : 0u;
+      packed = n >= kWalk * kPackedMin ? packed + 1u : 0u;
       PP(24);
       PPC(25);
       continue;
