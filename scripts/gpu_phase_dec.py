@@ -10,11 +10,7 @@ L = N.load()
 NB = int(__import__('os').environ.get('NB', '1024'))
 HC = __import__('os').environ.get('HC')
 # phase slots of the two wavefronts of a block (parsing wavefront first)
-names = ['0 before fill barrier', '1 wait: fill barrier', '2 copier: out-of-buffer matches', '3 copier: matches', '4 copier: flush',
-         '5 parser: chain + lane fields', '6 parser: literals', '7 wait: batch barrier', '8 copier: slide', '9 wait: slide barrier',
-         '10 copier: general loop', '11 wait: general barrier', '12', '13', '14', '15 total cycles',
-         '16 parse: window', '17 parse: four-chunk steps', '18 parse: single-token steps', '19 parse: lane fields', '20 parse: places and checks',
-         '21 count: four-chunk steps', '22 count: single-token steps', '23 count: parses', '24 parse: one-chunk steps', '25 count: one-chunk steps']
+from scripts.phase_names import names
 for arg in sys.argv[1:] or ['5']:
     idx = [int(x) for x in arg.split(',')]
     blocks = [corpus_block(i) for i in idx]
