@@ -274,6 +274,55 @@ def test_block_decoder_hand_built_sequences(codec, oracle, decode_form):
                 assert out[k, : len(o)].tobytes() == o, (len(prefix), strict, k, cases[k][:8])
 
 
+def test_block_decoder_short_matches_from_the_end_of_a_prefix(codec, oracle, decode_form):
+    """Hundreds of short sequences in a row (a token every three to five bytes: the decoder finds such tokens by
+    pointer jumping over four chunks at once) whose matches of at most sixteen bytes come from the last bytes of the
+    dictionary, far behind the output (one 16-byte load per match; a source within fifteen bytes of the prefix's
+    end must not be read past that end), next to matches of the same shape inside the block."""
+    import random
+
+    import torch
+    rng = random.Random(4242)
+    prefix = rng.randbytes(65536)
+    cases = []
+    for _ in range(40):
+        pos, seqs = 0, []
+        first = rng.choice([4200, 5000, 9000])
+        seqs.append((first, 4, 1))
+        pos = first + 4
+        for _ in range(rng.choice([150, 400])):
+            lit, ml = rng.randrange(0, 3), rng.randrange(4, 17)
+            pos += lit
+            if rng.random() < 0.7:
+                dist = pos + rng.randrange(1, 41)          # the last 40 bytes of the prefix
+            else:
+                dist = rng.randrange(4100, pos + 1) if pos > 4100 else 1  # far back inside the block
+            seqs.append((lit, ml, min(dist, 65535)))
+            pos += ml
+        seqs.append((rng.choice([1, 7]), 0, 0))
+        cases.append(seqs)
+    built = [block_of_sequences(c, rng, prefix) for c in cases]
+    slot = 65536
+    assert all(len(o) <= slot for _, o in built)
+    offs, blob = [], bytearray()
+    for c, _ in built:
+        offs.append(len(blob))
+        blob += c
+    blob += bytes(64)
+    comp = torch.tensor(np.frombuffer(bytes(blob), dtype=np.uint8).copy(), device="cuda")
+    sizes = torch.tensor([len(c) for c, _ in built], dtype=torch.int32, device="cuda")
+    offsets = torch.tensor(offs, dtype=torch.int64, device="cuda")
+    expected = torch.tensor([len(o) for _, o in built], dtype=torch.int32, device="cuda")
+    d = torch.tensor(np.frombuffer(prefix, dtype=np.uint8).copy(), device="cuda")
+    out, out_len, status = codec.decompress_blocks(comp, sizes, slot, comp_offsets=offsets, expected=expected,
+                                                   strict=False, dictionary=d)
+    out, out_len, status = out.cpu().numpy(), out_len.cpu().numpy(), status.cpu().numpy()
+    for k, (c, o) in enumerate(built):
+        assert oracle.block_decompress_into(c, prefix, len(prefix) + len(o))[len(prefix):] == o
+        assert int(status[k]) == 0 and int(out_len[k]) == len(o), k
+        assert out[k, : len(o)].tobytes() == o, k
+
+
 def test_block_decoder_short_sequence_blocks_fuzz(codec, oracle, decode_form):
     """Blocks made of thousands of short sequences (text through the HC encoder) take the
     decoder's second kernel, which decodes groups of sequences per step: status and bytes
