@@ -1050,11 +1050,11 @@ constexpr uint32_t kFarPieces = 16;
 #ifndef LZ4MI_FAR_SHORT
 #define LZ4MI_FAR_SHORT 1  // 0: every out-of-buffer match goes through the pieces (A/B builds)
 #endif
-template <bool HAS_PREFIX, uint32_t D>
+template <bool HAS_PREFIX, uint32_t D, typename Between>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
-                                         uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane) {
+                                         uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane,
+                                         Between between) {
   uint64_t fm = ballot(q.far);
-  if (!fm) return;
   // Short matches (text-like data through a strong encoder: eight bytes per match at distances all over the
   // block, so four of five are out of the buffer) would each take a piece of 64 lanes below.
   // One lane per match instead: a single 16-byte load (any alignment) per lane brings every short match of the
@@ -1063,15 +1063,19 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
   // touches the prefix's last 15 bytes would read past that buffer: it stays with the pieces below.
   // (Issuing this load in front of the first round of pieces, so that a batch with both kinds waits for memory
   // once, keeps six more registers alive across that loop and the kernel spills: measured twice as slow.)
-  if (LZ4MI_FAR_SHORT) {
+  // `between` is work of the caller's that neither reads nor writes what the matches here write (a wavefront on its
+  // own: the batch's literal copies); it runs while the short matches' load is in flight.
+  {
     const int64_t ap = (int64_t)op_start + q.sp;
-    const bool fs = q.far && q.ml <= 16u && (!HAS_PREFIX || ap >= 0 || ap + 16 <= 0);
+    const bool fs = LZ4MI_FAR_SHORT && q.far && q.ml <= 16u && (!HAS_PREFIX || ap >= 0 || ap + 16 <= 0);
     const uint64_t sm = ballot(fs);
-    if ((uint32_t)__builtin_popcountll(sm) >= 4u) {
-      typedef u32x4 u32x4_any __attribute__((aligned(1)));
-      typedef __attribute__((address_space(1))) u32x4_any g_v4any;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (fs) v = *(const g_v4any *)((HAS_PREFIX && ap < 0) ? prefix + ((int64_t)prefix_len + ap) : dst + ap);
+    const bool shorts = (uint32_t)__builtin_popcountll(sm) >= 4u;
+    typedef u32x4 u32x4_any __attribute__((aligned(1)));
+    typedef __attribute__((address_space(1))) u32x4_any g_v4any;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (shorts && fs) v = *(const g_v4any *)((HAS_PREFIX && ap < 0) ? prefix + ((int64_t)prefix_len + ap) : dst + ap);
+    between();
+    if (shorts) {
       const uint32_t d0 = q.o_mat + sneg, n = fs ? q.ml : 0u;
 #pragma unroll
       for (uint32_t t = 0; t < 16u; t++) {
@@ -1080,9 +1084,9 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
       }
       vm_quiesce();
       fm &= ~sm;
-      if (!fm) return;
     }
   }
+  if (!fm) return;
   int32_t cs = 0;            // the match being cut into pieces: source position, buffer offset, bytes left
   uint32_t cd = 0, cn = 0;
   for (;;) {
@@ -1343,8 +1347,8 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       const BatchPlan bp = parse_batch<kBatchOut>(src, in_end, ip, op, cap, back_limit, lo, fl, cw, tl, lane, pc, q);
       general = bp.general;
       if (bp.nb) {
-        copy_far<HAS_PREFIX, kStgBytes>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
-        copy_literals<kStgBytes>(cw, stg, sneg, q, lane);
+        copy_far<HAS_PREFIX, kStgBytes>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane,
+                                        [&]() __attribute__((always_inline)) { copy_literals<kStgBytes>(cw, stg, sneg, q, lane); });
         copy_matches<kStgBytes>(stg, sneg, bp.nb, q, lane);
         // ---- the batch goes to memory in aligned 16-byte pieces
         fl = stg_flush(stg, out, sneg, fl, bp.b1, false, lane);
@@ -1446,7 +1450,7 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
           q.dist = sh->desc[cur][3][lane];
           if (lane >= nb) { q.ml = 0; q.far = false; q.dist = 1; }
           prio_by_left(in_end - ip);
-          copy_far<HAS_PREFIX, D>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane);
+          copy_far<HAS_PREFIX, D>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane, []() {});
           PH(2);
           copy_matches<D>(stg, sneg, nb, q, lane);
           PH(3);
