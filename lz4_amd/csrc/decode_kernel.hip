@@ -1047,10 +1047,13 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
 // lane), sixteen pieces per round trip whichever matches they belong to.  (Data with long distances, and every
 // linked block near its start, has most of its matches here: the round trips are what that costs.)
 constexpr uint32_t kFarPieces = 16;
+#ifndef LZ4MI_FAR_EARLY
+#define LZ4MI_FAR_EARLY 8  // pieces of longer out-of-buffer matches loaded in front of the caller's work
+#endif
 #ifndef LZ4MI_FAR_SHORT
 #define LZ4MI_FAR_SHORT 1  // 0: every out-of-buffer match goes through the pieces (A/B builds)
 #endif
-template <bool HAS_PREFIX, uint32_t D, typename Between>
+template <bool HAS_PREFIX, uint32_t D, uint32_t E, typename Between>
 __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64_t op_start, const uint8_t *__restrict__ prefix,
                                          uint32_t prefix_len, uint32_t sneg, const SeqLane &q, uint32_t lane,
                                          Between between) {
@@ -1061,10 +1064,28 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
   // batch in one instruction and one round trip; the bytes behind a match's end are read and dropped (its source
   // lies more than the history in front of the output, so they are inside the output buffer).  A source that
   // touches the prefix's last 15 bytes would read past that buffer: it stays with the pieces below.
-  // (Issuing this load in front of the first round of pieces, so that a batch with both kinds waits for memory
-  // once, keeps six more registers alive across that loop and the kernel spills: measured twice as slow.)
   // `between` is work of the caller's that neither reads nor writes what the matches here write (a wavefront on its
-  // own: the batch's literal copies); it runs while the short matches' load is in flight.
+  // own: the batch's literal copies); it runs while the short matches' load and a first round of E pieces of the
+  // longer ones are in flight, so most batches wait for memory once, behind other work.
+  int32_t cs = 0;            // the match being cut into pieces: source position, buffer offset, bytes left
+  uint32_t cd = 0, cn = 0;
+  const auto next_piece = [&](int32_t &s_, uint32_t &d_, uint32_t &n_) __attribute__((always_inline)) {
+    if (cn == 0 && fm) {
+      const uint32_t j = (uint32_t)__builtin_ctzll(fm);
+      fm &= fm - 1ull;
+      cs = (int32_t)rdlane((uint32_t)q.sp, j);
+      cd = rdlane(q.o_mat, j) + sneg;
+      cn = rdlane(q.ml, j);
+    }
+    const uint32_t n = cn < kWave ? cn : kWave;
+    s_ = cs; d_ = cd; n_ = n;
+    cs += (int32_t)n; cd += n; cn -= n;
+  };
+  const auto piece_load = [&](int32_t s_, uint32_t n_) __attribute__((always_inline)) -> uint32_t {
+    if (!n_) return 0u;  // lanes past the end read the last byte again
+    const int64_t ap = (int64_t)op_start + s_ + (int64_t)(lane < n_ ? lane : n_ - 1u);
+    return (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
+  };
   {
     const int64_t ap = (int64_t)op_start + q.sp;
     const bool fs = LZ4MI_FAR_SHORT && q.far && q.ml <= 16u && (!HAS_PREFIX || ap >= 0 || ap + 16 <= 0);
@@ -1074,6 +1095,18 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
     typedef __attribute__((address_space(1))) u32x4_any g_v4any;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (shorts && fs) v = *(const g_v4any *)((HAS_PREFIX && ap < 0) ? prefix + ((int64_t)prefix_len + ap) : dst + ap);
+    if (shorts) fm &= ~sm;
+    constexpr uint32_t EA = E ? E : 1u;  // (no zero-length arrays)
+    int32_t es[EA];
+    uint32_t ed[EA], en[EA], ev[EA];
+#pragma unroll
+    for (uint32_t u = 0; u < EA; u++) es[u] = 0, ed[u] = 0, en[u] = 0, ev[u] = 0;
+    if (E && fm) {
+#pragma unroll
+      for (uint32_t u = 0; u < E; u++) next_piece(es[u], ed[u], en[u]);
+#pragma unroll
+      for (uint32_t u = 0; u < E; u++) ev[u] = piece_load(es[u], en[u]);
+    }
     between();
     if (shorts) {
       const uint32_t d0 = q.o_mat + sneg, n = fs ? q.ml : 0u;
@@ -1082,39 +1115,22 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
         if ((t == 8u || t == 12u) && !ballot(t < n)) break;
         stg[t < n ? d0 + t : D + lane] = (uint8_t)(v[t >> 2] >> (8u * (t & 3u)));
       }
-      vm_quiesce();
-      fm &= ~sm;
     }
+#pragma unroll
+    for (uint32_t u = 0; u < E; u++)
+      if (en[u]) stg[lane < en[u] ? ed[u] + lane : D + lane] = (uint8_t)ev[u];
+    if (shorts || (E && en[0])) vm_quiesce();
   }
-  if (!fm) return;
-  int32_t cs = 0;            // the match being cut into pieces: source position, buffer offset, bytes left
-  uint32_t cd = 0, cn = 0;
+  if (cn == 0 && !fm) return;
   for (;;) {
     int32_t ps[kFarPieces];
     uint32_t pd[kFarPieces], pn[kFarPieces];
 #pragma unroll
-    for (uint32_t u = 0; u < kFarPieces; u++) {
-      if (cn == 0 && fm) {
-        const uint32_t j = (uint32_t)__builtin_ctzll(fm);
-        fm &= fm - 1ull;
-        cs = (int32_t)rdlane((uint32_t)q.sp, j);
-        cd = rdlane(q.o_mat, j) + sneg;
-        cn = rdlane(q.ml, j);
-      }
-      const uint32_t n = cn < kWave ? cn : kWave;
-      ps[u] = cs; pd[u] = cd; pn[u] = n;
-      cs += (int32_t)n; cd += n; cn -= n;
-    }
+    for (uint32_t u = 0; u < kFarPieces; u++) next_piece(ps[u], pd[u], pn[u]);
     if (pn[0] == 0) break;
     uint32_t v[kFarPieces];
 #pragma unroll
-    for (uint32_t u = 0; u < kFarPieces; u++) {
-      v[u] = 0;
-      if (pn[u]) {  // lanes past the end read the last byte again
-        const int64_t ap = (int64_t)op_start + ps[u] + (int64_t)(lane < pn[u] ? lane : pn[u] - 1u);
-        v[u] = (HAS_PREFIX && ap < 0) ? prefix[(int64_t)prefix_len + ap] : dst[ap];
-      }
-    }
+    for (uint32_t u = 0; u < kFarPieces; u++) v[u] = piece_load(ps[u], pn[u]);
 #pragma unroll
     for (uint32_t u = 0; u < kFarPieces; u++)
       if (pn[u]) stg[lane < pn[u] ? pd[u] + lane : D + lane] = (uint8_t)v[u];
@@ -1347,7 +1363,7 @@ __device__ __forceinline__ int32_t decode_block(const uint8_t *__restrict__ src,
       const BatchPlan bp = parse_batch<kBatchOut>(src, in_end, ip, op, cap, back_limit, lo, fl, cw, tl, lane, pc, q);
       general = bp.general;
       if (bp.nb) {
-        copy_far<HAS_PREFIX, kStgBytes>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane,
+        copy_far<HAS_PREFIX, kStgBytes, LZ4MI_FAR_EARLY>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane,
                                         [&]() __attribute__((always_inline)) { copy_literals<kStgBytes>(cw, stg, sneg, q, lane); });
         copy_matches<kStgBytes>(stg, sneg, bp.nb, q, lane);
         // ---- the batch goes to memory in aligned 16-byte pieces
@@ -1450,7 +1466,7 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
           q.dist = sh->desc[cur][3][lane];
           if (lane >= nb) { q.ml = 0; q.far = false; q.dist = 1; }
           prio_by_left(in_end - ip);
-          copy_far<HAS_PREFIX, D>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane, []() {});
+          copy_far<HAS_PREFIX, D, 0>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane, []() {});  // nothing to do meanwhile: all pieces in rounds of sixteen
           PH(2);
           copy_matches<D>(stg, sneg, nb, q, lane);
           PH(3);
