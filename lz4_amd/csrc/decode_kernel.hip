@@ -779,9 +779,11 @@ __device__ __forceinline__ BatchPlan parse_batch(const uint8_t *__restrict__ src
   // ---- chain of token starts.  Only where the tokens are is found here, under the assumption that no
   // match length has a second extension byte; the positions go into a list, lane j then reads sequence j
   // in full, and a sequence whose real successor is not the next position of the list ends the batch.
-  // Two ways to step: where tokens are dense, lane p of a 64-byte chunk parses byte a + p as a token
-  // and the real starts are followed with one cross-lane read each; where literal runs are long (one
-  // token per chunk), the token is read into scalar registers and parsed there.
+  // Three ways to step: where tokens are dense, lane p parses the bytes a + p and a + 64 + p of two 64-byte
+  // chunks as tokens and the real starts are followed with one cross-lane read each; where they are packed
+  // (kPackedMin per chunk, kPackedRun steps in a row) four chunks are taken at once by pointer jumping
+  // (chain_four_chunks); where literal runs are long (one token per chunk), the token is read into scalar
+  // registers and parsed there.
   uint32_t a = ip - (uint32_t)wb, count = 0, tot = 0;
   bool stopped = false;  // the chain ends at a token (at a) that is not one for the batch, or not inside the window
   bool dense = pc.dense;
