@@ -1206,21 +1206,22 @@ __device__ __forceinline__ void copy_matches(lds_u8 *stg, uint32_t sneg, uint32_
   }
   // A match of at most 64 bytes that does not overlap its source (nearly every match of text-like data) is one read
   // and one write; bit 31 of the length marks the others (a period to repeat, or more than one piece).
+  lds_u8 *const at_lane = stg + lane, *const dummy = stg + D + lane;
   const auto one = [&](uint32_t j, uint32_t mf) __attribute__((always_inline)) {
-    const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j) + lane;
-    if (!(mf >> 31)) {
-      const uint32_t v = stg[ms + lane];
-      stg[lane < mf ? md : D + lane] = (uint8_t)v;
-      return;
-    }
-    const uint32_t m = mf & 0x7fffffffu;
-    const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
-    uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
-    for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
-      const uint32_t v = stg[ms + r];
-      stg[k0 + lane < m ? md + k0 : D + lane] = (uint8_t)v;
-      r += step;
-      r = r >= per ? r - per : r;
+    const uint32_t ms = rdlane(m_src, j), md = rdlane(m_dst, j);
+    if (__builtin_expect(!(mf >> 31), 1)) {
+      const uint32_t v = at_lane[ms];
+      *(lane < mf ? at_lane + md : dummy) = (uint8_t)v;
+    } else {
+      const uint32_t m = mf & 0x7fffffffu;
+      const uint32_t per = rdlane(m_per, j), step = rdlane(m_step, j);
+      uint32_t r = lane - __umul24(__umul24(lane, rdlane(m_mg, j)) >> 16, per);  // lane mod dist
+      for (uint32_t k0 = 0; k0 < m; k0 += kWave) {
+        const uint32_t v = stg[ms + r];
+        *(k0 + lane < m ? at_lane + md + k0 : dummy) = (uint8_t)v;
+        r += step;
+        r = r >= per ? r - per : r;
+      }
     }
   };
   m_todo |= (ovl || m_todo > kWave) ? 0x80000000u : 0u;
