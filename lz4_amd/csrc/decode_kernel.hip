@@ -1012,12 +1012,13 @@ __device__ __forceinline__ void copy_literals(const lds_u8 *cw, lds_u8 *stg, uin
     const uint32_t toff = head + 4u * body;
     const uint32_t t4 = cw32(cw, lsx + toff);
     const uint32_t nfirst = mid ? head : n1;  // bytes taken from the front (at most six)
+    lds_u8 *const at_front = stg + d0, *const at_back = stg + (d0 + toff - 3u), *const dummy = stg + D + lane;
 #pragma unroll
-    for (uint32_t i = 0; i < 6; i++) {
+    for (uint32_t i = 0; i < 6; i++) {  // (the byte's place is the store's constant offset)
       const bool front = i < nfirst;
       const bool back = mid && i >= 3u && i - 3u < tail;
       const uint32_t v = front ? (uint32_t)(f8 >> (8u * i)) : t4 >> (8u * (i - 3u < 3u ? i - 3u : 0u));
-      stg[front ? d0 + i : back ? d0 + toff + (i - 3u) : D + lane] = (uint8_t)v;
+      (front ? at_front : back ? at_back : dummy)[i] = (uint8_t)v;
     }
   }
   // runs longer than 64 bytes, one after the other: bytes 56.. of the run, 256 bytes per step, the same way
@@ -1111,16 +1112,18 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
     }
     between();
     if (shorts) {
-      const uint32_t d0 = q.o_mat + sneg, n = fs ? q.ml : 0u;
+      // (one base per lane and the byte's place as the store's constant offset: the dummy slot has room for it)
+      const uint32_t n = fs ? q.ml : 0u;
+      lds_u8 *const to = stg + (q.o_mat + sneg), *const dummy = stg + D + lane;
 #pragma unroll
       for (uint32_t t = 0; t < 16u; t++) {
         if ((t == 8u || t == 12u) && !ballot(t < n)) break;
-        stg[t < n ? d0 + t : D + lane] = (uint8_t)(v[t >> 2] >> (8u * (t & 3u)));
+        (t < n ? to : dummy)[t] = (uint8_t)(v[t >> 2] >> (8u * (t & 3u)));
       }
     }
 #pragma unroll
     for (uint32_t u = 0; u < E; u++)
-      if (en[u]) stg[lane < en[u] ? ed[u] + lane : D + lane] = (uint8_t)ev[u];
+      if (en[u]) *(lane < en[u] ? stg + lane + ed[u] : stg + D + lane) = (uint8_t)ev[u];
     if (shorts || (E && en[0])) vm_quiesce();
   }
   if (cn == 0 && !fm) return;
@@ -1135,7 +1138,7 @@ __device__ __forceinline__ void copy_far(lds_u8 *stg, const uint8_t *dst, uint64
     for (uint32_t u = 0; u < kFarPieces; u++) v[u] = piece_load(ps[u], pn[u]);
 #pragma unroll
     for (uint32_t u = 0; u < kFarPieces; u++)
-      if (pn[u]) stg[lane < pn[u] ? pd[u] + lane : D + lane] = (uint8_t)v[u];
+      if (pn[u]) *(lane < pn[u] ? stg + lane + pd[u] : stg + D + lane) = (uint8_t)v[u];
     vm_quiesce();
     if (cn == 0 && !fm) break;
   }
@@ -1469,7 +1472,7 @@ __device__ __forceinline__ int32_t decode_block_pair(const uint8_t *__restrict__
           q.dist = sh->desc[cur][3][lane];
           if (lane >= nb) { q.ml = 0; q.far = false; q.dist = 1; }
           prio_by_left(in_end - ip);
-          copy_far<HAS_PREFIX, D, 0>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane, []() {});  // nothing to do meanwhile: all pieces in rounds of sixteen
+          copy_far<HAS_PREFIX, D, LZ4MI_FAR_EARLY>(stg, dst, op_start, prefix, prefix_len, sneg, q, lane, []() {});  // (no work meanwhile, but both kinds of loads in one round trip)
           PH(2);
           copy_matches<D>(stg, sneg, nb, q, lane);
           PH(3);
